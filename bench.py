@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Benchmark of the WaveEnv integrator hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): TwoDim(15f0, 700), triple-ring design
+space, RandomPosGaussianSource, dt = 1e-5, 100 integration steps per environment action, RandomDesignPolicy.
+One bench "step" = one env(action) = 100 RK4 integration steps of the 700^2 grid = 49.0 M cell-updates, with the
+wave-speed field assembly, source injection, energy reductions and frame capture that belong to it.  All inputs are
+resident in HBM when the timed region starts (the only host->device traffic per action is the ~100 KB coefficient
+table; the only device->host traffic is the 101x3 energy trace).
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), each rank runs its own environment (weak scaling:
+independent episodes); the design-space block is broadcast from rank 0 before the timed region and the
+energy traces are all-gathered after the last step inside it.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+
+B_ALG = 104.0          # algorithmic bytes per cell-update: 48 r + 48 w state, 4 c, 4 source shape
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+N_GRID = 700
+STEPS_PER_ACTION = 100
+
+
+def cpu_baseline(n_steps: int):
+    """The C oracle ("port" of the reference algorithm, 1 core like the reference's single-threaded Julia CPU path) timed
+    on this host on a bounded sample of the same workload."""
+    import c_oracle as co
+    import waves_oracle as wo
+    f32 = np.float32
+    dim = wo.TwoDim.from_size(15.0, N_GRID)
+    rng = np.random.default_rng(0)
+    ds = wo.build_triple_ring_design_space()
+    a = wo.rand_design(ds, rng)
+    b = ds(a, wo.rand_design(wo.build_action_space(a, 0.25), rng))
+    flat = lambda d: np.concatenate([wo.stacked_cylinders(d).pos, wo.stacked_cylinders(d).r[:, None],
+                                     wo.stacked_cylinders(d).c[:, None]], 1).astype(f32)
+    G = wo.build_normal(wo.build_grid(dim), np.array([[-10.0, 3.0]]), np.array([0.3]), np.array([1.0]))
+    sx = wo.build_pml_profile(dim.x, 2.0, 20000.0)
+    ts = wo.build_tspan(0.0, 1e-5, n_steps)
+    st = np.zeros((12, N_GRID, N_GRID), f32)
+    t0 = time.perf_counter()
+    co.integrate(dim.x, dim.y, sx, sx, wo.WATER, 1e-5, st, ts, G=wo.to_abi(G), freq=1000.0, d0=flat(a), d1=flat(b),
+                 ti=0.0, tf=ts[-1], nthreads=1)
+    dt = time.perf_counter() - t0
+    return {"value": round(N_GRID * N_GRID * n_steps / dt / 1e6, 3), "unit": "Mcell-updates/s", "cores": 1,
+            "kind": "port",
+            "sample": f"{n_steps} integration steps of the same 700^2 triple-ring workload ({dt:.1f} s), "
+                      "oracle/waves_oracle.c single thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20, help="timed env actions (100 integration steps each)")
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--impl", default="auto", choices=["auto", "staged", "fused"])
+    ap.add_argument("--cpu-steps", type=int, default=40, help="integration steps of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--grid", type=int, default=N_GRID)
+    args = ap.parse_args()
+
+    import torch  # first: the HIP runtime both torch and libwaves_amd use is then torch's
+    import waves_jl_amd as w
+    from waves_jl_amd import dist as wd
+
+    rank, local_rank, world = wd.init()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    ngrid = args.grid
+    dev = local_rank if torch.cuda.device_count() > local_rank else 0
+    torch.cuda.set_device(dev)
+
+    # --- environment: rank 0 owns the design-space block, everyone else receives it over RCCL
+    ds = w.build_triple_ring_design_space() if rank == 0 else None
+    ds = wd.broadcast_design_space(ds, src=0)
+    dim = w.TwoDim(15.0, ngrid)
+    src = w.RandomPosGaussianSource(w.build_grid(dim), [[-10.0, -10.0]], [[-10.0, 10.0]], [0.3], [1.0], 1000.0,
+                                    rng=np.random.default_rng(2 + 1000 * rank))
+    total_actions = args.warmup + args.steps
+    env = w.WaveEnv(dim, design_space=ds, source=src, integration_steps=STEPS_PER_ACTION, actions=total_actions + 8,
+                    device=dev, impl=args.impl, rng=np.random.default_rng(1000 * rank), return_fields=False)
+    policy = w.RandomDesignPolicy(env.action_space(), np.random.default_rng(1 + 1000 * rank))
+    env.reset()
+
+    for _ in range(args.warmup):
+        env(policy(env))
+    if world > 1:
+        wd.gather_signals(env.signal)  # warm the communicator up outside the timed region
+
+    wd.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sigs = []
+    dev_ms = 0.0
+    for _ in range(args.steps):
+        env(policy(env))
+        sigs.append(env.signal)
+        dev_ms += env.ctx.timing()["total_ms"]
+    all_sig = wd.gather_signals(np.stack(sigs))
+    torch.cuda.synchronize()
+    wd.barrier()
+    elapsed = wd.max_over_ranks(time.perf_counter() - t0)
+
+    cells = ngrid * ngrid
+    cell_updates = world * cells * STEPS_PER_ACTION * args.steps
+    value = cell_updates / elapsed / 1e6
+
+    # --- roofline of the dominant kernel, measured live with HIP events on the ctx's stream (profiling mode brackets
+    # every step kernel; it is a separate pass so the timed region above is not perturbed)
+    out = None
+    if rank == 0:
+        impl = env.ctx.timing()["impl"]
+        env.ctx.set_profiling(True)
+        kms, launches = 0.0, 0
+        for _ in range(3):
+            env(policy(env))
+            t = env.ctx.timing()
+            kms += t["step_kernel_ms"]
+            launches += t["step_kernel_launches"]
+        env.ctx.set_profiling(False)
+        avg_ms = kms / launches
+        units_per_launch = cells if impl == "fused" else cells / 4.0   # staged: one RK stage = 1/4 cell-update per cell
+        alg_bytes = B_ALG * units_per_launch
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(impl)
+            except Exception:
+                traffic = None
+        kname = "k_step_fused" if impl == "fused" else "k_stage"
+        out = {
+            "metric": "Mcell-updates/s (700^2 grid, 100 integ steps)",
+            "value": round(value, 2),
+            "unit": "Mcell-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"TwoDim(15.0f0, {ngrid}) + triple-ring design_space, RandomPosGaussianSource, "
+                                   f"{STEPS_PER_ACTION} integration steps per env action, RandomDesignPolicy",
+                       "impl": impl, "envs_per_gpu": 1,
+                       "device_ms_per_step": round(dev_ms / args.steps, 4)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kname,
+                         "avg_kernel_us": round(avg_ms * 1e3, 3),
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "whole_job_frac": round(B_ALG * value * 1e6 / world / (HBM_PEAK_GBS * 1e9), 4)},
+            "signal_checksum": float(np.sum(all_sig[0][-1])),
+        }
+        if world == 1 and args.cpu_steps > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
+    wd.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    wd.finalize()
+
+
+if __name__ == "__main__":
+    main()

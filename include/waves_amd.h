@@ -1,0 +1,164 @@
+/* waves_amd.h -- C ABI of the MI355X-native WaveEnv integrator (libwaves_amd.so).
+ *
+ * Drop-in boundary for the hot path of gladisor/Waves.jl (reference citations are
+ * relative to the reference checkout, e.g. src/dynamics.jl:37-53).  The reference's
+ * interface is a set of Julia callable structs whose coefficient inputs are opaque
+ * closures (theta = [C, F], src/env.jl:99,102).  Closures cannot cross a C ABI, so the
+ * boundary is drawn at the parametric data those closures are built from:
+ *
+ *   C(t) = speed(DesignInterpolator(initial, final, ti, tf)(t), grid, c0)   -> wv_set_design
+ *   F(t) = shape .* sin(2f0*pi*t*freq)                                      -> wv_set_source_*
+ *
+ * Conventions
+ *   - every function returns an int status (WV_OK == 0); no C++ exception crosses the ABI;
+ *     wv_last_error() gives the message of the last failure.
+ *   - all pointer arguments are CALLER-OWNED HOST memory, copied during the call and never
+ *     retained; outputs go to caller-allocated buffers of the documented size; NULL means
+ *     "not wanted" where documented.
+ *   - arrays are fp32 in the reference's memory layout: Julia (x, y, field[, frame])
+ *     column-major, i.e. x contiguous, then y, then field.  A "state" is 12*nx*ny floats in
+ *     the field order of src/dynamics.jl:179-188: U,Vx,Vy,Psix,Psiy,Omega (total), then the
+ *     same six for the incident wave.
+ *   - one ctx = one device + one HIP stream; calls on a ctx are not re-entrant; different
+ *     ctxs may be driven from different threads/processes.
+ *   - the library has NO CPU fallback: with no usable gfx950 device wv_create fails with
+ *     WV_ERR_NO_DEVICE.
+ */
+#ifndef WAVES_AMD_H
+#define WAVES_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WV_ABI_VERSION 1
+#define WV_NFIELDS 12 /* src/dynamics.jl:185-187 */
+#define WV_NFRAMES 3  /* src/env.jl:54,116 */
+#define WV_FRAMESKIP 10 /* src/env.jl:90 */
+
+typedef struct wv_ctx wv_ctx;
+
+enum wv_status {
+    WV_OK = 0,
+    WV_ERR_INVALID = 1,   /* bad argument (the reference would throw an AssertionError/BoundsError/MethodError) */
+    WV_ERR_HIP = 2,       /* a HIP runtime call failed */
+    WV_ERR_NO_DEVICE = 3, /* no usable GPU: there is no CPU fallback */
+    WV_ERR_NOMEM = 4,
+    WV_ERR_STATE = 5      /* call sequence error (e.g. wv_integrate_end without _begin) */
+};
+
+/* which integrator implementation runs wv_integrate */
+enum wv_impl {
+    WV_IMPL_AUTO = 0,   /* fastest verified path */
+    WV_IMPL_STAGED = 1, /* one kernel per Runge-Kutta stage (simple, the in-library cross-check) */
+    WV_IMPL_FUSED = 2   /* all four RK stages of a step fused in one LDS-tiled kernel */
+};
+
+/* Replaces the constructor arguments of
+ *   AcousticDynamics(dim, c0, pml_width, pml_scale)   src/dynamics.jl:141-149
+ *   Integrator(runge_kutta, dyn, dt)                  src/dynamics.jl:18-22
+ * as WaveEnv's ctor builds them (src/env.jl:37-67). */
+typedef struct wv_config {
+    int nx, ny;      /* size(dim): length(dim.x), length(dim.y)   src/dims.jl:70-72 */
+    float c0;        /* ambient wave speed (WATER = 1531f0)         src/designs.jl:13 */
+    float dt;        /* Integrator.dt (1f-5)                        src/env.jl:47 */
+    float pml_width; /* 2f0                                         src/env.jl:43 */
+    float pml_scale; /* 20000f0                                     src/env.jl:44 */
+    int device;      /* HIP device ordinal (replaces Flux.device!(n), scripts/data.jl:33) */
+    int impl;        /* enum wv_impl */
+} wv_config;
+
+/* timing of the last wv_integrate on this ctx, measured with HIP events on the ctx's stream */
+typedef struct wv_timing {
+    double total_ms;        /* first enqueue -> last kernel of the call */
+    double step_kernel_ms;  /* sum of the durations of the per-step integrator kernels (profiling mode only, else 0) */
+    int step_kernel_launches;
+    int steps;
+    int impl;               /* implementation that ran */
+    int reserved;
+} wv_timing;
+
+int wv_abi_version(void);
+/* message of the last failure on this ctx; with ctx == NULL, of the last failure on this thread that had no ctx
+ * (wv_create).  Replaces Julia exceptions (src/env.jl:52 @assert, MethodErrors). */
+const char *wv_last_error(const wv_ctx *ctx);
+int wv_device_count(int *count);
+
+/* AcousticDynamics + Integrator construction.  x[nx], y[ny] are dim.x / dim.y (src/dims.jl:56-60) passed verbatim:
+ * the library derives the gradient coefficients (src/operators.jl:10-22 -- uses x only, like build_gradient(dim)),
+ * the PML profile (src/pml.jl:21-29 -- sigma_y is the transposed x profile, src/dynamics.jl:161-162, so nx must
+ * equal ny exactly as in the reference), the Dirichlet mask (src/dims.jl:117-124) and dx*dy (src/dims.jl:126-127). */
+int wv_create(const wv_config *cfg, const float *x, const float *y, wv_ctx **out);
+int wv_destroy(wv_ctx *ctx);
+
+/* dyn.pml as the 1-D profiles it is made of: sigma_x[i] (nx) and sigma_y[j] (ny).  src/pml.jl:21-29 */
+int wv_get_pml(wv_ctx *ctx, float *sigma_x, float *sigma_y);
+int wv_set_pml(wv_ctx *ctx, const float *sigma_x, const float *sigma_y);
+/* dOmega = get_dx(dim) * get_dy(dim), the factor of the energy traces.  src/env.jl:108 */
+int wv_get_cell_area(wv_ctx *ctx, float *dOmega);
+
+/* env.wave (nx, ny, 12, 3).  src/env.jl:17,54.  The integrator's initial condition is the LAST frame
+ * (env.wave[:, :, :, end], src/env.jl:102). */
+int wv_set_frames(wv_ctx *ctx, const float *wave /* 12*nx*ny*3 */);
+int wv_get_frames(wv_ctx *ctx, float *wave /* 12*nx*ny*3 */);
+/* last frame only == the current state `ui` of Integrator(ui, tspan, theta).  src/dynamics.jl:37 */
+int wv_set_state(wv_ctx *ctx, const float *u /* 12*nx*ny */);
+int wv_get_state(wv_ctx *ctx, float *u /* 12*nx*ny */);
+/* `env.wave *= 0f0` of reset!.  src/env.jl:81-88 (design and source re-randomisation are host-side policy). */
+int wv_reset(wv_ctx *ctx);
+
+/* F = Source(shape, freq) (src/sources.jl:10-23); shape == NULL selects NoSource (src/sources.jl:7-8). */
+int wv_set_source_shape(wv_ctx *ctx, const float *shape /* nx*ny or NULL */, float freq);
+/* F = RandomPosGaussianSource after reset!: shape = build_normal(grid, mu, sigma, a) built on the device.
+ * mu is K x 2 in Julia's column-major layout (mu[k], then mu[K + k]).  src/sources.jl:41-51, src/utils.jl:12-18 */
+int wv_set_gaussian_source(wv_ctx *ctx, int K, const float *mu, const float *sigma, const float *a, float freq);
+int wv_get_source_shape(wv_ctx *ctx, float *shape /* nx*ny */);
+
+/* C = t -> speed(DesignInterpolator(initial, final, ti, tf)(t), grid, c0).  src/env.jl:95-99, src/designs.jl:274-292.
+ * A design is M cylinders (a Cloak is passed stacked: config cylinders then the core, src/designs.jl:228,133-138):
+ * pos is M x 2 column-major (all x, then all y, like Julia's Matrix), r and c have M entries.  M == 0 is NoDesign
+ * (C(t) = c0, src/designs.jl:63). */
+int wv_set_design(wv_ctx *ctx, int M, const float *pos_initial, const float *r_initial, const float *c_initial,
+                  const float *pos_final, const float *r_final, const float *c_final, float ti, float tf);
+
+/* The closures evaluated at one time (for tests / drop-in of speed() and the source call). */
+int wv_speed_field(wv_ctx *ctx, float t, float *out /* nx*ny */);   /* src/designs.jl:110-116 via :287-292 */
+int wv_source_field(wv_ctx *ctx, float t, float *out /* nx*ny */);  /* src/sources.jl:67-69 */
+
+/* d/dx (axis 0: `grad * u`) or d/dy (axis 1: `(grad * u')'`) of one (nx, ny) plane.  src/operators.jl:45-46 */
+int wv_gradient(wv_ctx *ctx, int axis, const float *u /* nx*ny */, float *out /* nx*ny */);
+/* (dyn::AcousticDynamics{TwoDim})(x, t, theta): k = f(x, t).  src/dynamics.jl:179-188 */
+int wv_rhs(wv_ctx *ctx, const float *x /* 12*nx*ny */, float t, float *k /* 12*nx*ny */);
+
+/* sol = iter(env.wave[:,:,:,end], tspan, [C, F]) + the reductions of src/env.jl:105-116.
+ *   tspan[nsteps+1]   the tabulated times (src/dynamics.jl:5-7); step i uses tspan[i], not an accumulated t.
+ *   capture_frames    != 0: env.wave <- states at nsteps-20, nsteps-10, nsteps (src/env.jl:116; needs nsteps >= 20,
+ *                     else WV_ERR_INVALID like Julia's BoundsError); == 0: only the last frame is replaced.
+ *   signal            (nsteps+1) x 3 row-major [tot, inc, sc] energies x dOmega at every saved time incl. the initial
+ *                     one (src/env.jl:105-114), or NULL.
+ *   u_tot, u_inc      (nsteps+1) planes of nx*ny (sol[:,:,1,:], sol[:,:,7,:], src/env.jl:105-106,120) or NULL.
+ * Synchronous: outputs are ready on return. */
+int wv_integrate(wv_ctx *ctx, const float *tspan, int nsteps, int capture_frames, float *signal, float *u_tot,
+                 float *u_inc);
+/* The same split in two so that several ctxs on one device overlap: _begin enqueues all device work and returns,
+ * _end waits and copies the outputs.  Exactly one _end per _begin. */
+int wv_integrate_begin(wv_ctx *ctx, const float *tspan, int nsteps, int capture_frames, int want_signal,
+                       int want_fields);
+int wv_integrate_end(wv_ctx *ctx, float *signal, float *u_tot, float *u_inc);
+
+/* measurement and plumbing */
+int wv_set_profiling(wv_ctx *ctx, int on); /* bracket every step kernel with HIP events (slower; for roofline) */
+int wv_get_timing(wv_ctx *ctx, wv_timing *out);
+int wv_set_stream(wv_ctx *ctx, void *hip_stream); /* run on a caller-owned hipStream_t (NULL: back to the ctx's own) */
+int wv_synchronize(wv_ctx *ctx);
+/* raw device pointer of env.wave (12*nx*ny*3 floats) for zero-copy interop (RCCL, torch); valid until wv_destroy */
+int wv_device_frames(wv_ctx *ctx, void **dptr, size_t *bytes);
+/* raw device pointer of the source shape (nx*ny floats) */
+int wv_device_source_shape(wv_ctx *ctx, void **dptr, size_t *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAVES_AMD_H */

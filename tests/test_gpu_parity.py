@@ -1,0 +1,315 @@
+"""Parity tests proper: the HIP path, called through the C ABI (ctypes), against the CPU oracle on the same seeded
+inputs.  Fields, RHS, gradient, wave-speed mask and PML profile are compared BIT-EXACTLY (np.array_equal; +0 == -0):
+the kernels keep the reference's fp32 operation order and are built with -ffp-contract=off.  The stated fp32
+tolerance of the north star therefore only applies to the two reductions/transcendentals whose order/rounding the
+reference itself leaves open:  energy traces rel. 1e-5 (sum order), Gaussian source shape 2 ulp (exp)."""
+import numpy as np
+import pytest
+
+import c_oracle as co
+import waves_jl_amd as w
+import waves_oracle as wo
+from helpers import (flat_design, oracle_integrate, oracle_to_mirror_design, random_state, rel_err,
+                     small_moving_design)
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+IMPLS = ["staged", "fused"]
+ENERGY_RTOL = 1e-5
+
+
+def make_ctx(n, impl="auto", pml=(2.0, 20000.0), size=15.0, dt=1e-5, c0=wo.WATER):
+    dim = wo.TwoDim.from_size(size, n)
+    ctx = w._ffi.Context(dim.x, dim.y, c0=c0, dt=dt, pml_width=pml[0], pml_scale=pml[1], device=0, impl=impl)
+    return dim, ctx
+
+
+def set_design(ctx, d0, d1, ti, tf):
+    a, b = wo.stacked_cylinders(d0), wo.stacked_cylinders(d1)
+    ctx.set_design((a.pos, a.r, a.c), (b.pos, b.r, b.c), ti, tf)
+
+
+def test_device_is_gfx950_and_library_loaded():
+    assert w.device_count() >= 1
+    dim, ctx = make_ctx(64)
+    assert ctx.cell_area() == f32(wo.get_dx(dim) * wo.get_dy(dim))
+    ctx.close()
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+def test_reference_gradient_testset_on_device(axis):
+    """test/operators.jl:4-30 carried to both axes of the device stencil (see the NOTE in test_oracle_reference_kat)"""
+    n = 1024
+    dim, ctx = make_ctx(n, size=25.0)
+    dx = wo.get_dx(dim)
+    X, Y = np.meshgrid(dim.x, dim.y, indexing="ij")
+    coord = X if axis == 0 else Y
+    g = wo.build_gradient(dim.x)
+    for fn, dfn, rel in ((lambda x: x * x, lambda x: f32(2.0) * x, False), (np.sin, np.cos, False), (np.exp, np.exp, True)):
+        u = fn(coord).astype(f32)
+        d = ctx.gradient(axis, u)
+        true = dfn(coord).astype(f32)
+        assert np.all(np.abs(d - true) / (true if rel else f32(1)) < dx)
+        assert np.array_equal(d, wo.dx(g, u) if axis == 0 else wo.dy(g, u))   # bit-exact vs the oracle
+    ctx.close()
+
+
+def test_pml_profile_bit_exact():
+    for n, width in ((256, 2.0), (700, 2.0), (300, 4.0), (128, 1.0)):
+        dim, ctx = make_ctx(n, pml=(width, 20000.0))
+        sx, sy = ctx.pml()
+        ref = wo.build_pml_profile(dim.x, width, 20000.0)
+        assert np.array_equal(sx, ref) and np.array_equal(sy, ref)
+        ctx.close()
+
+
+def test_speed_field_bit_exact_moving_design():
+    rng = np.random.default_rng(11)
+    dim, ctx = make_ctx(700)
+    grid = wo.build_grid(dim)
+    ds = wo.build_triple_ring_design_space()
+    a = wo.rand_design(ds, rng)
+    b = ds(a, wo.rand_design(wo.build_action_space(a, 0.25), rng))
+    it = wo.DesignInterpolator(a, b, f32(0.003), f32(0.004))
+    set_design(ctx, a, b, it.ti, it.tf)
+    flips = 0
+    prev = None
+    for t in (0.0029, 0.003, 0.003005, 0.00333, 0.0037775, 0.004, 0.0041):
+        c = ctx.speed_field(t)
+        ref = wo.speed(it(f32(t)), grid, wo.WATER)
+        assert np.array_equal(c, ref)
+        if prev is not None:
+            flips += int((c != prev).sum())
+        prev = c
+    assert flips > 100   # the radii really moved cells across the mask
+    # overlapping cylinders add (designs.jl:114), position-moving designs
+    d0, d1 = small_moving_design(rng, 5, spread=1.0)
+    set_design(ctx, d0, d1, 0.0, 1e-3)
+    it2 = wo.DesignInterpolator(d0, d1, f32(0.0), f32(1e-3))
+    for t in (0.0, 4.5e-4, 1e-3):
+        assert np.array_equal(ctx.speed_field(t), wo.speed(it2(f32(t)), grid, wo.WATER))
+    ctx.set_design(None, None, 0.0, 0.0)
+    assert np.all(ctx.speed_field(0.0) == wo.WATER)
+    ctx.close()
+
+
+def test_gaussian_source_shape_and_time_factor():
+    dim, ctx = make_ctx(700)
+    grid = wo.build_grid(dim)
+    mu = np.array([[-10.0, 3.3], [2.0, -1.0]], f32)
+    sig = np.array([0.3, 0.7], f32)
+    a = np.array([1.0, 0.5], f32)
+    ctx.set_gaussian_source(mu, sig, a, 1000.0)
+    G = ctx.source_shape()
+    ref = wo.build_normal(grid, mu, sig, a)
+    ulp = np.spacing(np.abs(ref).astype(f32)) + np.finfo(f32).tiny
+    assert np.all(np.abs(G - ref) <= 2 * ulp * 2)      # exp rounding: <= 2 ulp per term
+    assert rel_err(G, ref) < 3e-7
+    for t in (0.0, 1e-5, 0.00123, 0.0199):
+        s = wo.source_time_factor(f32(t), f32(1000.0))
+        assert np.array_equal(ctx.source_field(t), G * s)
+        assert s == co.source_factor(t, 1000.0)
+    ctx.close()
+
+
+@pytest.mark.parametrize("n", [64, 257])
+def test_rhs_bit_exact(n):
+    """dyn(x, t, theta), src/dynamics.jl:179-188, on a random state with every field populated"""
+    rng = np.random.default_rng(n)
+    dim, ctx = make_ctx(n)
+    grid = wo.build_grid(dim)
+    d0, d1 = small_moving_design(rng, 4)
+    G = wo.build_normal(grid, np.array([[0.5, -0.5]]), np.array([0.8]), np.array([2.0]))
+    ctx.set_source_shape(G, 1000.0)
+    set_design(ctx, d0, d1, 0.0, 1e-3)
+    x = random_state(rng, n, n)
+    t = f32(3.3e-4)
+    k = ctx.rhs(x, t)
+    dyn = wo.AcousticDynamics.build(dim, wo.WATER, 2.0, 20000.0)
+    it = wo.DesignInterpolator(d0, d1, f32(0.0), f32(1e-3))
+    src = wo.Source(G, f32(1000.0))
+    ref = dyn(x, t, [lambda tt: wo.speed(it(tt), grid, wo.WATER), lambda tt: src(tt)])
+    assert np.array_equal(k, ref)
+    ctx.close()
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_config1_256_no_design_100_steps(impl):
+    """BASELINE config 1: TwoDim(15, 256), single Gaussian source at (-10, 0), no design, 100 steps"""
+    dim, ctx = make_ctx(256, impl)
+    grid = wo.build_grid(dim)
+    G = wo.build_normal(grid, np.array([[-10.0, 0.0]]), np.array([0.3]), np.array([1.0]))
+    ctx.set_source_shape(G, 1000.0)
+    ctx.set_design(None, None, 0.0, 0.0)
+    ts = wo.build_tspan(0.0, 1e-5, 100)
+    sig, ut, ui = ctx.integrate(ts, capture_frames=True, want_signal=True, want_fields=True)
+    st, rsig, fr = oracle_integrate(dim, np.zeros((12, 256, 256), f32), ts, G=G, freq=1000.0, frame_steps=(80, 90, 100))
+    frames = ctx.get_frames()
+    for k in range(3):
+        assert np.array_equal(wo.to_abi(frames[:, :, :, k]), fr[k])
+    assert np.abs(st[0]).max() > 0.5
+    assert np.array_equal(frames[:, :, :6, 2], frames[:, :, 6:, 2])      # no design: total == incident
+    assert np.all(sig[:, 2] == 0)
+    assert rel_err(sig[:, :2], rsig[:, :2]) < ENERGY_RTOL
+    assert np.array_equal(ut[:, :, 100], frames[:, :, 0, 2]) and np.array_equal(ui[:, :, 90], frames[:, :, 6, 1])
+    assert np.all(ut[:, :, 0] == 0)
+    t = ctx.timing()
+    assert t["impl"] == impl and t["steps"] == 100 and t["total_ms"] > 0
+    ctx.close()
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("n,steps", [(96, 40), (200, 30)])
+def test_moving_design_from_random_state(impl, n, steps):
+    """moving radii + positions, source on, every one of the 12 fields (PML auxiliaries included) non-zero at t0"""
+    rng = np.random.default_rng(n + steps)
+    dim, ctx = make_ctx(n, impl)
+    grid = wo.build_grid(dim)
+    d0, d1 = small_moving_design(rng, 4, spread=4.0)
+    G = wo.build_normal(grid, np.array([[-3.0, 1.0]]), np.array([0.5]), np.array([1.0]))
+    u0 = random_state(rng, n, n, scale=0.1)
+    ts = wo.build_tspan(f32(0.002), 1e-5, steps)
+    ctx.set_source_shape(G, 1000.0)
+    set_design(ctx, d0, d1, ts[0], ts[-1])
+    ctx.set_state(u0)
+    sig, _, _ = ctx.integrate(ts, capture_frames=True)
+    st, rsig, fr = oracle_integrate(dim, wo.to_abi(u0), ts, G=G, freq=1000.0, d0=flat_design(d0), d1=flat_design(d1),
+                                    ti=ts[0], tf=ts[-1], frame_steps=(steps - 20, steps - 10, steps))
+    frames = ctx.get_frames()
+    for k in range(3):
+        assert np.array_equal(wo.to_abi(frames[:, :, :, k]), fr[k]), f"frame {k}"
+    assert np.array_equal(wo.to_abi(ctx.get_state()), st)
+    assert not np.array_equal(st[0], st[6])
+    assert rel_err(sig, rsig) < ENERGY_RTOL
+    ctx.close()
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_env_rollout_matches_oracle_env(impl):
+    """WaveEnv mirror vs the oracle's WaveEnv: 3 actions of 25 steps, triple-ring cloak, source next to the rings so
+    that the scattered field is non-trivial.  Same seeded designs/actions are injected on both sides."""
+    n, steps = 160, 25
+    odim = wo.TwoDim.from_size(15.0, n)
+    ogrid = wo.build_grid(odim)
+    mu = np.array([[0.5, 0.3]], f32)
+    osrc = wo.RandomPosGaussianSource(ogrid, mu, mu, np.array([0.3], f32), np.array([1.0], f32), f32(1000.0))
+    orng = np.random.default_rng(42)
+    oenv = wo.WaveEnv(odim, design_space=wo.build_triple_ring_design_space(), source=osrc, integration_steps=steps,
+                      actions=3, rng=orng, resolution=(32, 32))
+    oenv.reset()
+    dim = w.TwoDim(15.0, n)
+    src = w.RandomPosGaussianSource(w.build_grid(dim), mu, mu, [0.3], [1.0], 1000.0, rng=np.random.default_rng(1))
+    env = w.WaveEnv(dim, design_space=w.build_triple_ring_design_space(), source=src, integration_steps=steps,
+                    actions=3, rng=np.random.default_rng(2), resolution=(32, 32), impl=impl)
+    env.reset()
+    env.design = oracle_to_mirror_design(w, oenv.design)
+    # the device builds the Gaussian itself; feed the oracle the device's shape so the fields can be compared exactly
+    osrc.shape = np.array(env.source.shape)
+    assert rel_err(osrc.shape, wo.build_normal(ogrid, mu, osrc.sigma, osrc.a)) < 3e-7
+    pol = wo.RandomDesignPolicy(oenv.action_space(), np.random.default_rng(3))
+    while not oenv.is_terminated():
+        assert not env.is_terminated()
+        oact = pol(oenv)
+        ots, ointerp, outot, ouinc = oenv(oact)
+        ts, interp, utot, uinc = env(oracle_to_mirror_design(w, oact))
+        assert np.array_equal(ts, ots) and env.time_step == oenv.time_step
+        assert np.array_equal(env.wave, oenv.wave)
+        assert np.array_equal(utot, outot) and np.array_equal(uinc, ouinc)
+        assert rel_err(env.signal, oenv.signal) < ENERGY_RTOL
+        assert np.array_equal(env.design.stacked().r, wo.stacked_cylinders(oenv.design).r)
+    assert env.is_terminated() and oenv.signal[-1, 2] > 1e-6 * oenv.signal[-1, 0] > 0
+    assert abs(env.reward() - oenv.reward()) <= ENERGY_RTOL * abs(oenv.reward())
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_config2_700_triple_ring_100_steps(impl):
+    """BASELINE config 2 (the benchmark workload): TwoDim(15, 700), triple-ring design, Gaussian source, 100 steps.
+    Run twice: from the zero state (the env's first action) and continued from the resulting state."""
+    rng = np.random.default_rng(0)
+    dim, ctx = make_ctx(700, impl)
+    grid = wo.build_grid(dim)
+    ds = wo.build_triple_ring_design_space()
+    a = wo.rand_design(ds, rng)
+    b = ds(a, wo.rand_design(wo.build_action_space(a, 0.25), np.random.default_rng(1)))
+    mu = np.array([[-10.0, np.random.default_rng(2).uniform(-10, 10)]], f32)
+    G = wo.build_normal(grid, mu, np.array([0.3], f32), np.array([1.0], f32))
+    ctx.set_source_shape(G, 1000.0)
+    state = np.zeros((12, 700, 700), f32)
+    for act in range(2):
+        ts = wo.build_tspan(f32(f32(100 * act) * f32(1e-5)), 1e-5, 100)
+        d0, d1 = (a, b) if act == 0 else (b, a)
+        set_design(ctx, d0, d1, ts[0], ts[-1])
+        sig, _, _ = ctx.integrate(ts, capture_frames=True)
+        state, rsig, fr = oracle_integrate(dim, state, ts, G=G, freq=1000.0, d0=flat_design(d0), d1=flat_design(d1),
+                                           ti=ts[0], tf=ts[-1], frame_steps=(80, 90, 100))
+        frames = ctx.get_frames()
+        for k in range(3):
+            assert np.array_equal(wo.to_abi(frames[:, :, :, k]), fr[k]), f"action {act} frame {k}"
+        assert rel_err(sig[:, :2], rsig[:, :2]) < ENERGY_RTOL
+        assert np.abs(sig[:, 2] - rsig[:, 2]).max() <= ENERGY_RTOL * rsig[:, 0].max()
+    ctx.close()
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_pulse_through_design_scattering(impl):
+    """scripts/pml.jl-style initial pulse placed next to a cylinder: total != incident, scattered energy grows"""
+    n = 192
+    dim, ctx = make_ctx(n, impl, size=5.0, pml=(1.0, 20000.0))
+    grid = wo.build_grid(dim)
+    ic = wo.build_normal(grid, np.array([[-1.0, 0.0]]), np.array([0.3]), np.array([1.0]))
+    u0 = np.zeros((n, n, 12), f32, order="F")
+    u0[:, :, 0] = ic
+    u0[:, :, 6] = ic
+    cyl = wo.Cylinders(np.array([[0.8, 0.1]], f32), np.array([0.7], f32), np.array([1032.0], f32))
+    ctx.set_source_shape(None, 0.0)
+    set_design(ctx, cyl, cyl, 0.0, 1.0)
+    ctx.set_state(u0)
+    ts = wo.build_tspan(0.0, 1e-5, 150)
+    sig, _, _ = ctx.integrate(ts)
+    st, rsig, _ = oracle_integrate(dim, wo.to_abi(u0), ts, pml=(1.0, 20000.0), d0=flat_design(cyl), d1=flat_design(cyl),
+                                   ti=0.0, tf=1.0)
+    assert np.array_equal(wo.to_abi(ctx.get_state()), st)
+    assert rel_err(sig, rsig) < ENERGY_RTOL
+    assert sig[-1, 2] > 1e-3 * sig[-1, 0] and sig[0, 2] == 0
+    ctx.close()
+
+
+def test_uniform_non_ambient_speed_and_integrator_mirror():
+    """Integrator-level use without an env (scripts/pml.jl:4-18): iter(wave, tspan, [t -> c, NoSource()])"""
+    n = 96
+    dim = w.TwoDim(5.0, n)
+    odim = wo.TwoDim.from_size(5.0, n)
+    it = w.Integrator(w.runge_kutta, w.AcousticDynamics(dim, w.WATER, 1.0, 0.0), 1e-5)
+    wave = w.build_wave(dim, 12)
+    ic = wo.build_normal(wo.build_grid(odim), np.array([[0.0, 0.0]]), np.array([0.3]), np.array([1.0]))
+    wave[:, :, 0] = ic
+    wave[:, :, 6] = ic
+    ts = it.build_tspan(0.0, 30)
+    sol = it(wave, ts, [w.UniformSpeed(w.WATER), w.NoSource()], save=[0, 10, 30])
+    assert sol.shape == (n, n, 12, 3)
+    oit = wo.Integrator(wo.runge_kutta, wo.AcousticDynamics.build(odim, wo.WATER, 1.0, 0.0), f32(1e-5))
+    ref = oit(np.array(wave), ts, [lambda t: wo.WATER, wo.NoSource()], save={0, 10, 30})
+    assert np.array_equal(sol, ref)
+    # a different uniform speed for the total field only
+    sol2 = it(wave, ts, [w.UniformSpeed(1200.0), w.NoSource()], save=[30])
+    ref2 = oit(np.array(wave), ts, [lambda t: f32(1200.0), wo.NoSource()], save={30})
+    assert np.array_equal(sol2, ref2) and not np.array_equal(sol2[:, :, 0], sol2[:, :, 6])
+
+
+def test_error_behaviour():
+    dim, ctx = make_ctx(64)
+    ts = wo.build_tspan(0.0, 1e-5, 10)
+    with pytest.raises(w.WavesAmdError) as ei:          # Julia: BoundsError at src/env.jl:116
+        ctx.integrate(ts, capture_frames=True)
+    assert ei.value.status == w._ffi.WV_ERR_INVALID
+    ctx.integrate(ts, capture_frames=False)              # Integrator-level call is fine
+    ctx.integrate_begin(ts)
+    with pytest.raises(w.WavesAmdError) as ei:
+        ctx.set_state(np.zeros((64, 64, 12), f32))
+    assert ei.value.status == w._ffi.WV_ERR_STATE
+    ctx.integrate_end()
+    with pytest.raises(w.WavesAmdError):
+        ctx.integrate_end()
+    ctx.close()
+    with pytest.raises(AssertionError):                  # src/env.jl:52
+        w.WaveEnv(w.TwoDim(15.0, 64), design_space=w.build_triple_ring_design_space(), resolution=(128, 128))

@@ -1,0 +1,308 @@
+"""ctypes binding of libwaves_amd.so -- the C ABI declared in include/waves_amd.h.
+
+There is NO fallback: if the HIP library is missing or no gfx950 device is usable, every compute entry point raises
+(`WavesAmdError`).  Nothing here imports the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libwaves_amd.so")
+HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "include", "waves_amd.h"))
+
+WV_OK, WV_ERR_INVALID, WV_ERR_HIP, WV_ERR_NO_DEVICE, WV_ERR_NOMEM, WV_ERR_STATE = range(6)
+WV_IMPL_AUTO, WV_IMPL_STAGED, WV_IMPL_FUSED = 0, 1, 2
+IMPLS = {"auto": WV_IMPL_AUTO, "staged": WV_IMPL_STAGED, "fused": WV_IMPL_FUSED}
+
+
+class WavesAmdError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"libwaves_amd status {status}: {msg}")
+        self.status = status
+
+
+class wv_config(C.Structure):
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("c0", C.c_float), ("dt", C.c_float), ("pml_width", C.c_float),
+                ("pml_scale", C.c_float), ("device", C.c_int), ("impl", C.c_int)]
+
+
+class wv_timing(C.Structure):
+    _fields_ = [("total_ms", C.c_double), ("step_kernel_ms", C.c_double), ("step_kernel_launches", C.c_int),
+                ("steps", C.c_int), ("impl", C.c_int), ("reserved", C.c_int)]
+
+
+_fp = C.POINTER(C.c_float)
+_vp = C.c_void_p
+_lib = None
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source of the library for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else [])
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout)
+        print(r.stderr)
+    if r.returncode != 0:
+        raise RuntimeError("building libwaves_amd.so failed")
+    return LIB_PATH
+
+
+def _sig(L, name, argtypes, restype=C.c_int):
+    f = getattr(L, name)
+    f.argtypes = argtypes
+    f.restype = restype
+    return f
+
+
+def lib():
+    """Load libwaves_amd.so (fails loudly if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise WavesAmdError(-1, f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    ctx = _vp
+    _sig(L, "wv_abi_version", [])
+    _sig(L, "wv_last_error", [ctx], C.c_char_p)
+    _sig(L, "wv_device_count", [C.POINTER(C.c_int)])
+    _sig(L, "wv_create", [C.POINTER(wv_config), _fp, _fp, C.POINTER(ctx)])
+    _sig(L, "wv_destroy", [ctx])
+    _sig(L, "wv_get_pml", [ctx, _fp, _fp])
+    _sig(L, "wv_set_pml", [ctx, _fp, _fp])
+    _sig(L, "wv_get_cell_area", [ctx, _fp])
+    _sig(L, "wv_set_frames", [ctx, _fp])
+    _sig(L, "wv_get_frames", [ctx, _fp])
+    _sig(L, "wv_set_state", [ctx, _fp])
+    _sig(L, "wv_get_state", [ctx, _fp])
+    _sig(L, "wv_reset", [ctx])
+    _sig(L, "wv_set_source_shape", [ctx, _fp, C.c_float])
+    _sig(L, "wv_set_gaussian_source", [ctx, C.c_int, _fp, _fp, _fp, C.c_float])
+    _sig(L, "wv_get_source_shape", [ctx, _fp])
+    _sig(L, "wv_set_design", [ctx, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_float])
+    _sig(L, "wv_speed_field", [ctx, C.c_float, _fp])
+    _sig(L, "wv_source_field", [ctx, C.c_float, _fp])
+    _sig(L, "wv_gradient", [ctx, C.c_int, _fp, _fp])
+    _sig(L, "wv_rhs", [ctx, _fp, C.c_float, _fp])
+    _sig(L, "wv_integrate", [ctx, _fp, C.c_int, C.c_int, _fp, _fp, _fp])
+    _sig(L, "wv_integrate_begin", [ctx, _fp, C.c_int, C.c_int, C.c_int, C.c_int])
+    _sig(L, "wv_integrate_end", [ctx, _fp, _fp, _fp])
+    _sig(L, "wv_set_profiling", [ctx, C.c_int])
+    _sig(L, "wv_get_timing", [ctx, C.POINTER(wv_timing)])
+    _sig(L, "wv_set_stream", [ctx, _vp])
+    _sig(L, "wv_synchronize", [ctx])
+    _sig(L, "wv_device_frames", [ctx, C.POINTER(_vp), C.POINTER(C.c_size_t)])
+    _sig(L, "wv_device_source_shape", [ctx, C.POINTER(_vp), C.POINTER(C.c_size_t)])
+    _lib = L
+    return L
+
+
+def fptr(a):
+    return a.ctypes.data_as(_fp) if a is not None else None
+
+
+def f32c(a) -> np.ndarray:
+    """float32, contiguous in whatever order the array already has (C or F)."""
+    a = np.asarray(a, dtype=np.float32)
+    if a.flags.f_contiguous or a.flags.c_contiguous:
+        return a
+    return np.ascontiguousarray(a)
+
+
+def fortran(a, shape=None) -> np.ndarray:
+    """float32 array in the reference's (column-major) memory layout."""
+    a = np.asfortranarray(a, dtype=np.float32)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {tuple(a.shape)}")
+    return a
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = lib().wv_device_count(C.byref(n))
+    if rc != WV_OK:
+        return 0
+    return n.value
+
+
+class Context:
+    """One wv_ctx: one environment's device state on one GPU."""
+
+    def __init__(self, x, y, *, c0, dt, pml_width, pml_scale, device=0, impl="auto"):
+        L = lib()
+        self._L = L
+        self.x = np.ascontiguousarray(x, dtype=np.float32)
+        self.y = np.ascontiguousarray(y, dtype=np.float32)
+        self.nx, self.ny = len(self.x), len(self.y)
+        cfg = wv_config(self.nx, self.ny, float(c0), float(dt), float(pml_width), float(pml_scale), int(device),
+                        IMPLS[impl] if isinstance(impl, str) else int(impl))
+        h = _vp()
+        rc = L.wv_create(C.byref(cfg), fptr(self.x), fptr(self.y), C.byref(h))
+        if rc != WV_OK:
+            raise WavesAmdError(rc, (L.wv_last_error(None) or b"").decode())
+        self._h = h
+        self.device = int(device)
+
+    def _ck(self, rc):
+        if rc != WV_OK:
+            raise WavesAmdError(rc, (self._L.wv_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.wv_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- geometry-derived quantities
+    def pml(self):
+        sx = np.empty(self.nx, np.float32)
+        sy = np.empty(self.ny, np.float32)
+        self._ck(self._L.wv_get_pml(self._h, fptr(sx), fptr(sy)))
+        return sx, sy
+
+    def set_pml(self, sx, sy):
+        sx = np.ascontiguousarray(sx, np.float32)
+        sy = np.ascontiguousarray(sy, np.float32)
+        assert sx.shape == (self.nx,) and sy.shape == (self.ny,)
+        self._ck(self._L.wv_set_pml(self._h, fptr(sx), fptr(sy)))
+
+    def cell_area(self) -> np.float32:
+        v = C.c_float(0)
+        self._ck(self._L.wv_get_cell_area(self._h, C.byref(v)))
+        return np.float32(v.value)
+
+    # --- state.  Arrays use the reference's shapes, Fortran order: (nx, ny, 12[, 3])
+    def set_frames(self, wave):
+        w = fortran(wave, (self.nx, self.ny, 12, 3))
+        self._ck(self._L.wv_set_frames(self._h, fptr(w)))
+
+    def get_frames(self):
+        w = np.empty((self.nx, self.ny, 12, 3), np.float32, order="F")
+        self._ck(self._L.wv_get_frames(self._h, fptr(w)))
+        return w
+
+    def set_state(self, u):
+        w = fortran(u, (self.nx, self.ny, 12))
+        self._ck(self._L.wv_set_state(self._h, fptr(w)))
+
+    def get_state(self):
+        w = np.empty((self.nx, self.ny, 12), np.float32, order="F")
+        self._ck(self._L.wv_get_state(self._h, fptr(w)))
+        return w
+
+    def reset(self):
+        self._ck(self._L.wv_reset(self._h))
+
+    # --- coefficients
+    def set_source_shape(self, shape, freq):
+        s = fortran(shape, (self.nx, self.ny)) if shape is not None else None
+        self._ck(self._L.wv_set_source_shape(self._h, fptr(s), float(freq)))
+
+    def set_gaussian_source(self, mu, sigma, a, freq):
+        mu = fortran(np.asarray(mu, np.float32).reshape(-1, 2))
+        sigma = np.ascontiguousarray(sigma, np.float32).reshape(-1)
+        a = np.ascontiguousarray(a, np.float32).reshape(-1)
+        K = len(sigma)
+        assert mu.shape == (K, 2) and a.shape == (K,)
+        self._ck(self._L.wv_set_gaussian_source(self._h, K, fptr(mu), fptr(sigma), fptr(a), float(freq)))
+
+    def source_shape(self):
+        s = np.empty((self.nx, self.ny), np.float32, order="F")
+        self._ck(self._L.wv_get_source_shape(self._h, fptr(s)))
+        return s
+
+    def set_design(self, initial, final, ti, tf):
+        """initial/final: (pos (M,2), r (M,), c (M,)) tuples or None (NoDesign)."""
+        if initial is None:
+            self._ck(self._L.wv_set_design(self._h, 0, None, None, None, None, None, None, float(ti), float(tf)))
+            return
+        arrs = []
+        for pos, r, c in (initial, final):
+            arrs += [fortran(np.asarray(pos, np.float32).reshape(-1, 2)), np.ascontiguousarray(r, np.float32).reshape(-1),
+                     np.ascontiguousarray(c, np.float32).reshape(-1)]
+        M = len(arrs[1])
+        for a in arrs:
+            assert a.shape[0] == M
+        self._ck(self._L.wv_set_design(self._h, M, *[fptr(a) for a in arrs], float(ti), float(tf)))
+
+    def speed_field(self, t):
+        o = np.empty((self.nx, self.ny), np.float32, order="F")
+        self._ck(self._L.wv_speed_field(self._h, float(t), fptr(o)))
+        return o
+
+    def source_field(self, t):
+        o = np.empty((self.nx, self.ny), np.float32, order="F")
+        self._ck(self._L.wv_source_field(self._h, float(t), fptr(o)))
+        return o
+
+    def gradient(self, axis, u):
+        u = fortran(u, (self.nx, self.ny))
+        o = np.empty((self.nx, self.ny), np.float32, order="F")
+        self._ck(self._L.wv_gradient(self._h, int(axis), fptr(u), fptr(o)))
+        return o
+
+    def rhs(self, x, t):
+        x = fortran(x, (self.nx, self.ny, 12))
+        k = np.empty((self.nx, self.ny, 12), np.float32, order="F")
+        self._ck(self._L.wv_rhs(self._h, fptr(x), float(t), fptr(k)))
+        return k
+
+    # --- integration
+    def integrate(self, tspan, *, capture_frames=False, want_signal=True, want_fields=False):
+        self.integrate_begin(tspan, capture_frames=capture_frames, want_signal=want_signal, want_fields=want_fields)
+        return self.integrate_end()
+
+    def integrate_begin(self, tspan, *, capture_frames=False, want_signal=True, want_fields=False):
+        ts = np.ascontiguousarray(tspan, np.float32).reshape(-1)
+        n = len(ts) - 1
+        self._pend = (n, bool(want_signal), bool(want_fields))
+        self._ck(self._L.wv_integrate_begin(self._h, fptr(ts), n, int(bool(capture_frames)), int(bool(want_signal)),
+                                            int(bool(want_fields))))
+
+    def integrate_end(self):
+        n, ws, wf = self._pend
+        sig = np.empty((n + 1, 3), np.float32) if ws else None
+        ut = np.empty((self.nx, self.ny, n + 1), np.float32, order="F") if wf else None
+        ui = np.empty((self.nx, self.ny, n + 1), np.float32, order="F") if wf else None
+        self._ck(self._L.wv_integrate_end(self._h, fptr(sig), fptr(ut), fptr(ui)))
+        return sig, ut, ui
+
+    # --- measurement / plumbing
+    def set_profiling(self, on: bool):
+        self._ck(self._L.wv_set_profiling(self._h, int(bool(on))))
+
+    def timing(self) -> dict:
+        t = wv_timing()
+        self._ck(self._L.wv_get_timing(self._h, C.byref(t)))
+        return {"total_ms": t.total_ms, "step_kernel_ms": t.step_kernel_ms,
+                "step_kernel_launches": t.step_kernel_launches, "steps": t.steps,
+                "impl": {1: "staged", 2: "fused"}.get(t.impl, str(t.impl))}
+
+    def set_stream(self, stream_handle):
+        self._ck(self._L.wv_set_stream(self._h, _vp(stream_handle) if stream_handle else None))
+
+    def synchronize(self):
+        self._ck(self._L.wv_synchronize(self._h))
+
+    def device_frames(self):
+        p, n = _vp(), C.c_size_t(0)
+        self._ck(self._L.wv_device_frames(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def device_source_shape(self):
+        p, n = _vp(), C.c_size_t(0)
+        self._ck(self._L.wv_device_source_shape(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value

@@ -1,0 +1,759 @@
+// C-ABI host layer of libwaves_amd.so (include/waves_amd.h).  Owns the device memory of one environment, builds the
+// per-stage coefficient tables on the host exactly as the reference's closures would evaluate them, and enqueues the
+// integrator kernels on the ctx's HIP stream.  No CPU compute fallback exists: every numerical result comes from a
+// gfx950 kernel.
+#include "../../include/waves_amd.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "fused.h"
+#include "kernels.h"
+
+using namespace wv;
+
+struct wv_ctx {
+    wv_config cfg{};
+    int nx = 0, ny = 0;
+    size_t P = 0, N = 0;  // plane, state (12 planes)
+    hipStream_t own_stream = nullptr, stream = nullptr;
+
+    std::vector<float> x, y, sx, sy;
+    float dOmega = 0.0f;
+    Grid grid{};
+
+    float *d_x = nullptr, *d_y = nullptr, *d_sx = nullptr, *d_sy = nullptr;
+    float *d_frames = nullptr;           // env.wave: 3 states
+    float *d_scratch[2] = {nullptr, nullptr};
+    float *d_yA = nullptr, *d_yB = nullptr, *d_acc = nullptr;  // staged implementation only
+    float *d_G = nullptr;                // source shape
+    bool has_source = false;
+    float freq = 0.0f;
+    float *d_plane[2] = {nullptr, nullptr};
+
+    // DesignInterpolator(initial, final, ti, tf), cylinders stacked: px, py, r, c per cylinder
+    int M = 0;
+    std::vector<float> d0, d1;
+    float ti = 0.0f, tf = 0.0f;
+
+    Cyl *d_cyl = nullptr;
+    size_t cyl_cap = 0;
+    std::vector<Cyl> h_cyl;
+    std::vector<float> h_sfac;
+    float *d_epart = nullptr;
+    size_t epart_cap = 0;
+    float *d_signal = nullptr;
+    size_t signal_cap = 0;
+    float *d_traj = nullptr;
+    size_t traj_cap = 0;
+    float *d_small = nullptr;  // gaussian parameters
+    size_t small_cap = 0;
+
+    FusedPlan *fused = nullptr;
+
+    bool pending = false;
+    int pend_nsteps = 0;
+    bool pend_signal = false, pend_fields = false;
+
+    bool profiling = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> kev;
+    wv_timing timing{};
+
+    std::string err;
+};
+
+static thread_local std::string g_err;
+
+static int fail(wv_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg; else g_err = msg;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                                  \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return fail((c), WV_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));             \
+    } while (0)
+
+#define CHECK_CTX(c)                                   \
+    do {                                               \
+        if (!(c)) return fail(nullptr, WV_ERR_INVALID, "ctx is NULL"); \
+        HIPCHK((c), hipSetDevice((c)->cfg.device));    \
+    } while (0)
+
+// ---- host-side restatement of the closures' scalar work (fp32, reference order, no FMA) -----------------------
+
+// src/operators.jl:10-22
+static Ops make_ops(const std::vector<float> &x)
+{
+    const int n = (int)x.size();
+    const float delta = (x[n - 1] - x[0]) / (float)(n - 1);
+    const float two_d = 2.0f * delta;
+    Ops o;
+    o.cm = -1.0f / two_d;
+    o.cp = 1.0f / two_d;
+    o.f0 = -3.0f / two_d; o.f1 = 4.0f / two_d; o.f2 = -1.0f / two_d;
+    o.b0 = 1.0f / two_d;  o.b1 = -4.0f / two_d; o.b2 = 3.0f / two_d;
+    return o;
+}
+
+// src/pml.jl:21-29 (1-D profile of the field that `repeat` tiles along y)
+static std::vector<float> make_pml(const std::vector<float> &xs, float width, float scale)
+{
+    const size_t n = xs.size();
+    std::vector<float> out(n);
+    const float pml_start = fabsf(xs[0]) - width;
+    float mn = INFINITY;
+    for (size_t i = 0; i < n; ++i) {
+        const float a = fabsf(xs[i]);
+        if (a > pml_start && a < mn) mn = a;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        const float a = fabsf(xs[i]);
+        float v = 0.0f;
+        if (a > pml_start) v = (a - mn) / width;
+        out[i] = ((v * v) * v) * scale;
+    }
+    return out;
+}
+
+// Flux.mean(diff(x)), src/dims.jl:126-127 (double accumulation, rounded once)
+static float mean_diff(const std::vector<float> &x)
+{
+    double s = 0.0;
+    for (size_t i = 1; i < x.size(); ++i) s += (double)(x[i] - x[i - 1]);
+    return (float)(s / (double)(x.size() - 1));
+}
+
+// DesignInterpolator call, src/designs.jl:287-292 with the algebra of :47-53: per scalar component
+//   v_i + ((v_f + (-1f0*v_i)) * (1f0/Dt)) * (clamp(t, ti, tf) - ti)
+static void design_at(const wv_ctx *c, float t, Cyl *out)
+{
+    float dt = c->tf - c->ti;
+    dt = dt > 0.0f ? dt : 1.0f;
+    const float inv_dt = 1.0f / dt;
+    const float tc = t < c->ti ? c->ti : (t > c->tf ? c->tf : t);
+    const float tau = tc - c->ti;
+    for (int m = 0; m < c->M; ++m) {
+        float v[4];
+        for (int k = 0; k < 4; ++k) {
+            const float vi = c->d0[4 * m + k], vf = c->d1[4 * m + k];
+            const float dy = vf + (-1.0f * vi);
+            v[k] = vi + (dy * inv_dt) * tau;
+        }
+        out[m].px = v[0];
+        out[m].py = v[1];
+        out[m].r2 = v[2] * v[2];  // `r .^ 2`, src/designs.jl:102
+        out[m].c = v[3];
+    }
+}
+
+// sin.(2.0f0 * pi * t * freq): ((2f0*pi)*t)*freq in fp32, accurately rounded sin.  src/sources.jl:21-22,67-69
+static float source_factor(float t, float freq)
+{
+    const float two_pi = 6.2831855f;
+    const float arg = (two_pi * t) * freq;
+    return (float)sin((double)arg);
+}
+
+template <class T>
+static int ensure(wv_ctx *c, T **p, size_t *cap, size_t need)
+{
+    if (need <= *cap) return WV_OK;
+    if (*p) HIPCHK(c, hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    HIPCHK(c, hipMalloc((void **)p, need * sizeof(T)));
+    *cap = need;
+    return WV_OK;
+}
+
+static float *frame(wv_ctx *c, int k) { return c->d_frames + (size_t)k * c->N; }
+
+// ---- ABI -------------------------------------------------------------------------------------------------
+
+extern "C" {
+
+int wv_abi_version(void) { return WV_ABI_VERSION; }
+
+const char *wv_last_error(const wv_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int wv_device_count(int *count)
+{
+    if (!count) return fail(nullptr, WV_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(nullptr, WV_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = n;
+    return WV_OK;
+}
+
+int wv_destroy(wv_ctx *c)
+{
+    if (!c) return WV_OK;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    float *bufs[] = {c->d_x, c->d_y, c->d_sx, c->d_sy, c->d_frames, c->d_scratch[0], c->d_scratch[1], c->d_yA, c->d_yB,
+                     c->d_acc, c->d_G, c->d_plane[0], c->d_plane[1], c->d_epart, c->d_signal, c->d_traj, c->d_small};
+    for (float *b : bufs)
+        if (b) (void)hipFree(b);
+    if (c->d_cyl) (void)hipFree(c->d_cyl);
+    if (c->fused) fused_destroy(c->fused);
+    for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return WV_OK;
+}
+
+int wv_create(const wv_config *cfg, const float *x, const float *y, wv_ctx **out)
+{
+    if (!cfg || !x || !y || !out) return fail(nullptr, WV_ERR_INVALID, "wv_create: NULL argument");
+    *out = nullptr;
+    if (cfg->nx < 8 || cfg->ny < 8) return fail(nullptr, WV_ERR_INVALID, "wv_create: nx and ny must be >= 8");
+    if (cfg->nx != cfg->ny)
+        return fail(nullptr, WV_ERR_INVALID,
+                    "wv_create: nx must equal ny (the reference uses the x gradient matrix and the transposed x PML "
+                    "profile for y: src/dynamics.jl:146,161-162)");
+    if (!(cfg->dt > 0.0f)) return fail(nullptr, WV_ERR_INVALID, "wv_create: dt must be > 0");
+    if (cfg->impl < WV_IMPL_AUTO || cfg->impl > WV_IMPL_FUSED) return fail(nullptr, WV_ERR_INVALID, "wv_create: bad impl");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, WV_ERR_NO_DEVICE,
+                    std::string("wv_create: no HIP device (") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0") +
+                        "); libwaves_amd has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, WV_ERR_INVALID, "wv_create: device ordinal out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return fail(nullptr, WV_ERR_HIP, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, WV_ERR_NO_DEVICE,
+                    std::string("wv_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 (MI355X) only");
+
+    wv_ctx *c = new (std::nothrow) wv_ctx();
+    if (!c) return fail(nullptr, WV_ERR_NOMEM, "wv_create: out of host memory");
+    c->cfg = *cfg;
+    c->nx = cfg->nx;
+    c->ny = cfg->ny;
+    c->P = (size_t)cfg->nx * cfg->ny;
+    c->N = c->P * kFields;
+    c->x.assign(x, x + c->nx);
+    c->y.assign(y, y + c->ny);
+    c->sx = make_pml(c->x, cfg->pml_width, cfg->pml_scale);
+    c->sy = c->sx;  // sigma_y = sigma_x' : the x profile indexed by j
+    c->dOmega = mean_diff(c->x) * mean_diff(c->y);
+
+#define CK(expr)                                                                                         \
+    do {                                                                                                 \
+        hipError_t e2_ = (expr);                                                                         \
+        if (e2_ != hipSuccess) {                                                                         \
+            std::string m_ = std::string(#expr) + ": " + hipGetErrorString(e2_);                         \
+            wv_destroy(c);                                                                               \
+            return fail(nullptr, e2_ == hipErrorOutOfMemory ? WV_ERR_NOMEM : WV_ERR_HIP, m_);            \
+        }                                                                                                \
+    } while (0)
+
+    CK(hipSetDevice(cfg->device));
+    CK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    CK(hipEventCreate(&c->ev0));
+    CK(hipEventCreate(&c->ev1));
+    CK(hipMalloc((void **)&c->d_x, c->nx * sizeof(float)));
+    CK(hipMalloc((void **)&c->d_y, c->ny * sizeof(float)));
+    CK(hipMalloc((void **)&c->d_sx, c->nx * sizeof(float)));
+    CK(hipMalloc((void **)&c->d_sy, c->ny * sizeof(float)));
+    CK(hipMalloc((void **)&c->d_frames, 3 * c->N * sizeof(float)));
+    CK(hipMalloc((void **)&c->d_scratch[0], c->N * sizeof(float)));
+    CK(hipMalloc((void **)&c->d_scratch[1], c->N * sizeof(float)));
+    CK(hipMalloc((void **)&c->d_yA, c->N * sizeof(float)));
+    CK(hipMalloc((void **)&c->d_yB, c->N * sizeof(float)));
+    CK(hipMalloc((void **)&c->d_acc, c->N * sizeof(float)));
+    CK(hipMalloc((void **)&c->d_G, c->P * sizeof(float)));
+    CK(hipMalloc((void **)&c->d_plane[0], c->P * sizeof(float)));
+    CK(hipMalloc((void **)&c->d_plane[1], c->P * sizeof(float)));
+    CK(hipMemcpy(c->d_x, c->x.data(), c->nx * sizeof(float), hipMemcpyHostToDevice));
+    CK(hipMemcpy(c->d_y, c->y.data(), c->ny * sizeof(float), hipMemcpyHostToDevice));
+    CK(hipMemcpy(c->d_sx, c->sx.data(), c->nx * sizeof(float), hipMemcpyHostToDevice));
+    CK(hipMemcpy(c->d_sy, c->sy.data(), c->ny * sizeof(float), hipMemcpyHostToDevice));
+    CK(hipMemset(c->d_frames, 0, 3 * c->N * sizeof(float)));
+    CK(hipMemset(c->d_G, 0, c->P * sizeof(float)));
+#undef CK
+
+    Grid &g = c->grid;
+    g.nx = c->nx;
+    g.ny = c->ny;
+    g.P = c->P;
+    g.ops = make_ops(c->x);
+    g.x = c->d_x;
+    g.y = c->d_y;
+    g.sx = c->d_sx;
+    g.sy = c->d_sy;
+    g.c0 = cfg->c0;
+    g.c0sq = cfg->c0 * cfg->c0;
+
+    c->fused = fused_create(g, c->sx.data(), c->sy.data());
+    if (!c->fused) {
+        wv_destroy(c);
+        return fail(nullptr, WV_ERR_HIP, "wv_create: fused plan allocation failed");
+    }
+    *out = c;
+    return WV_OK;
+}
+
+int wv_get_pml(wv_ctx *c, float *sigma_x, float *sigma_y)
+{
+    CHECK_CTX(c);
+    if (sigma_x) memcpy(sigma_x, c->sx.data(), c->nx * sizeof(float));
+    if (sigma_y) memcpy(sigma_y, c->sy.data(), c->ny * sizeof(float));
+    return WV_OK;
+}
+
+int wv_set_pml(wv_ctx *c, const float *sigma_x, const float *sigma_y)
+{
+    CHECK_CTX(c);
+    if (!sigma_x || !sigma_y) return fail(c, WV_ERR_INVALID, "wv_set_pml: NULL profile");
+    if (c->pending) return fail(c, WV_ERR_STATE, "wv_set_pml: an integrate is pending");
+    c->sx.assign(sigma_x, sigma_x + c->nx);
+    c->sy.assign(sigma_y, sigma_y + c->ny);
+    HIPCHK(c, hipMemcpy(c->d_sx, c->sx.data(), c->nx * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_sy, c->sy.data(), c->ny * sizeof(float), hipMemcpyHostToDevice));
+    fused_set_pml(c->fused, c->sx.data(), c->sy.data());
+    return WV_OK;
+}
+
+int wv_get_cell_area(wv_ctx *c, float *dOmega)
+{
+    CHECK_CTX(c);
+    if (!dOmega) return fail(c, WV_ERR_INVALID, "dOmega is NULL");
+    *dOmega = c->dOmega;
+    return WV_OK;
+}
+
+int wv_set_frames(wv_ctx *c, const float *wave)
+{
+    CHECK_CTX(c);
+    if (!wave) return fail(c, WV_ERR_INVALID, "wv_set_frames: NULL");
+    if (c->pending) return fail(c, WV_ERR_STATE, "wv_set_frames: an integrate is pending");
+    HIPCHK(c, hipMemcpyAsync(c->d_frames, wave, 3 * c->N * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    fused_state_changed(c->fused);
+    return WV_OK;
+}
+
+int wv_get_frames(wv_ctx *c, float *wave)
+{
+    CHECK_CTX(c);
+    if (!wave) return fail(c, WV_ERR_INVALID, "wv_get_frames: NULL");
+    HIPCHK(c, hipMemcpyAsync(wave, c->d_frames, 3 * c->N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WV_OK;
+}
+
+int wv_set_state(wv_ctx *c, const float *u)
+{
+    CHECK_CTX(c);
+    if (!u) return fail(c, WV_ERR_INVALID, "wv_set_state: NULL");
+    if (c->pending) return fail(c, WV_ERR_STATE, "wv_set_state: an integrate is pending");
+    HIPCHK(c, hipMemcpyAsync(frame(c, 2), u, c->N * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    fused_state_changed(c->fused);
+    return WV_OK;
+}
+
+int wv_get_state(wv_ctx *c, float *u)
+{
+    CHECK_CTX(c);
+    if (!u) return fail(c, WV_ERR_INVALID, "wv_get_state: NULL");
+    HIPCHK(c, hipMemcpyAsync(u, frame(c, 2), c->N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WV_OK;
+}
+
+int wv_reset(wv_ctx *c)
+{
+    CHECK_CTX(c);
+    if (c->pending) return fail(c, WV_ERR_STATE, "wv_reset: an integrate is pending");
+    HIPCHK(c, hipMemsetAsync(c->d_frames, 0, 3 * c->N * sizeof(float), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    fused_state_zeroed(c->fused);
+    return WV_OK;
+}
+
+int wv_set_source_shape(wv_ctx *c, const float *shape, float freq)
+{
+    CHECK_CTX(c);
+    if (c->pending) return fail(c, WV_ERR_STATE, "wv_set_source_shape: an integrate is pending");
+    c->has_source = shape != nullptr;
+    c->freq = freq;
+    if (shape) {
+        HIPCHK(c, hipMemcpyAsync(c->d_G, shape, c->P * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    } else {
+        HIPCHK(c, hipMemsetAsync(c->d_G, 0, c->P * sizeof(float), c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WV_OK;
+}
+
+int wv_set_gaussian_source(wv_ctx *c, int K, const float *mu, const float *sigma, const float *a, float freq)
+{
+    CHECK_CTX(c);
+    if (K < 1 || !mu || !sigma || !a) return fail(c, WV_ERR_INVALID, "wv_set_gaussian_source: bad arguments");
+    if (c->pending) return fail(c, WV_ERR_STATE, "wv_set_gaussian_source: an integrate is pending");
+    int rc = ensure(c, &c->d_small, &c->small_cap, (size_t)4 * K);
+    if (rc) return rc;
+    std::vector<float> h(4 * (size_t)K);
+    memcpy(h.data(), mu, 2 * K * sizeof(float));
+    memcpy(h.data() + 2 * K, sigma, K * sizeof(float));
+    memcpy(h.data() + 3 * K, a, K * sizeof(float));
+    HIPCHK(c, hipMemcpy(c->d_small, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    launch_gaussian(c->grid, K, c->d_small, c->d_small + 2 * K, c->d_small + 3 * K, c->d_G, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->has_source = true;
+    c->freq = freq;
+    return WV_OK;
+}
+
+int wv_get_source_shape(wv_ctx *c, float *shape)
+{
+    CHECK_CTX(c);
+    if (!shape) return fail(c, WV_ERR_INVALID, "wv_get_source_shape: NULL");
+    HIPCHK(c, hipMemcpyAsync(shape, c->d_G, c->P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WV_OK;
+}
+
+int wv_set_design(wv_ctx *c, int M, const float *pos_i, const float *r_i, const float *c_i, const float *pos_f,
+                  const float *r_f, const float *c_f, float ti, float tf)
+{
+    CHECK_CTX(c);
+    if (M < 0 || M > 4096) return fail(c, WV_ERR_INVALID, "wv_set_design: M out of range [0, 4096]");
+    if (M > 0 && (!pos_i || !r_i || !c_i || !pos_f || !r_f || !c_f)) return fail(c, WV_ERR_INVALID, "wv_set_design: NULL array");
+    if (c->pending) return fail(c, WV_ERR_STATE, "wv_set_design: an integrate is pending");
+    c->M = M;
+    c->ti = ti;
+    c->tf = tf;
+    c->d0.resize(4 * (size_t)M);
+    c->d1.resize(4 * (size_t)M);
+    for (int m = 0; m < M; ++m) {
+        c->d0[4 * m + 0] = pos_i[m];
+        c->d0[4 * m + 1] = pos_i[M + m];
+        c->d0[4 * m + 2] = r_i[m];
+        c->d0[4 * m + 3] = c_i[m];
+        c->d1[4 * m + 0] = pos_f[m];
+        c->d1[4 * m + 1] = pos_f[M + m];
+        c->d1[4 * m + 2] = r_f[m];
+        c->d1[4 * m + 3] = c_f[m];
+    }
+    return WV_OK;
+}
+
+int wv_speed_field(wv_ctx *c, float t, float *out)
+{
+    CHECK_CTX(c);
+    if (!out) return fail(c, WV_ERR_INVALID, "wv_speed_field: NULL");
+    if (c->pending) return fail(c, WV_ERR_STATE, "wv_speed_field: an integrate is pending");
+    int rc = ensure(c, &c->d_cyl, &c->cyl_cap, (size_t)(c->M > 0 ? c->M : 1));
+    if (rc) return rc;
+    c->h_cyl.resize(c->M > 0 ? c->M : 1);
+    design_at(c, t, c->h_cyl.data());
+    if (c->M > 0) HIPCHK(c, hipMemcpy(c->d_cyl, c->h_cyl.data(), c->M * sizeof(Cyl), hipMemcpyHostToDevice));
+    launch_speed_field(c->grid, c->d_cyl, c->M, c->d_plane[0], c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->d_plane[0], c->P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WV_OK;
+}
+
+int wv_source_field(wv_ctx *c, float t, float *out)
+{
+    CHECK_CTX(c);
+    if (!out) return fail(c, WV_ERR_INVALID, "wv_source_field: NULL");
+    if (c->pending) return fail(c, WV_ERR_STATE, "wv_source_field: an integrate is pending");
+    if (!c->has_source) {  // NoSource returns the scalar 0f0 (src/sources.jl:8)
+        memset(out, 0, c->P * sizeof(float));
+        return WV_OK;
+    }
+    launch_scale(c->d_G, source_factor(t, c->freq), c->d_plane[0], c->P, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->d_plane[0], c->P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WV_OK;
+}
+
+int wv_gradient(wv_ctx *c, int axis, const float *u, float *out)
+{
+    CHECK_CTX(c);
+    if (!u || !out || (axis != 0 && axis != 1)) return fail(c, WV_ERR_INVALID, "wv_gradient: bad arguments");
+    if (c->pending) return fail(c, WV_ERR_STATE, "wv_gradient: an integrate is pending");
+    HIPCHK(c, hipMemcpyAsync(c->d_plane[0], u, c->P * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    launch_gradient(c->grid, axis, c->d_plane[0], c->d_plane[1], c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->d_plane[1], c->P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WV_OK;
+}
+
+int wv_rhs(wv_ctx *c, const float *x, float t, float *k)
+{
+    CHECK_CTX(c);
+    if (!x || !k) return fail(c, WV_ERR_INVALID, "wv_rhs: NULL");
+    if (c->pending) return fail(c, WV_ERR_STATE, "wv_rhs: an integrate is pending");
+    int rc = ensure(c, &c->d_cyl, &c->cyl_cap, (size_t)(c->M > 0 ? c->M : 1));
+    if (rc) return rc;
+    c->h_cyl.resize(c->M > 0 ? c->M : 1);
+    design_at(c, t, c->h_cyl.data());
+    if (c->M > 0) HIPCHK(c, hipMemcpy(c->d_cyl, c->h_cyl.data(), c->M * sizeof(Cyl), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpyAsync(c->d_scratch[0], x, c->N * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    StageIO io{};
+    io.yin = c->d_scratch[0];
+    io.u = c->d_scratch[0];
+    io.acc = c->d_acc;
+    io.out = c->d_scratch[1];
+    io.G = c->has_source ? c->d_G : nullptr;
+    io.sfac = c->has_source ? source_factor(t, c->freq) : 0.0f;
+    io.cyl = c->d_cyl;
+    io.M = c->M;
+    io.a = 0.0f;
+    io.dt = c->cfg.dt;
+    launch_stage(c->grid, io, 4, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(k, c->d_scratch[1], c->N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WV_OK;
+}
+
+int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, int want_signal, int want_fields)
+{
+    CHECK_CTX(c);
+    if (c->pending) return fail(c, WV_ERR_STATE, "wv_integrate_begin: previous integrate not ended");
+    if (!tspan || nsteps < 1) return fail(c, WV_ERR_INVALID, "wv_integrate: tspan NULL or nsteps < 1");
+    if (capture && nsteps < 2 * WV_FRAMESKIP)
+        return fail(c, WV_ERR_INVALID,
+                    "wv_integrate: capture_frames needs nsteps >= 20 (sol[:, :, :, end-20:10:end], src/env.jl:116)");
+    const int M = c->M;
+    const float dt = c->cfg.dt;
+    const float hdt = 0.5f * dt;
+    const int impl = c->cfg.impl == WV_IMPL_FUSED ? WV_IMPL_FUSED : WV_IMPL_STAGED;  // AUTO -> staged until the fused kernel is verified
+
+    // per-stage coefficient tables: stage times t, t + 0.5f0*dt, t + dt (src/dynamics.jl:10-13)
+    c->h_sfac.assign(3 * (size_t)nsteps, 0.0f);
+    c->h_cyl.resize(3 * (size_t)nsteps * (M > 0 ? M : 1));
+    for (int s = 0; s < nsteps; ++s) {
+        const float t = tspan[s];
+        const float tq[3] = {t, t + hdt, t + dt};
+        for (int q = 0; q < 3; ++q) {
+            if (c->has_source) c->h_sfac[3 * s + q] = source_factor(tq[q], c->freq);
+            if (M > 0) design_at(c, tq[q], c->h_cyl.data() + (size_t)(3 * s + q) * M);
+        }
+    }
+    int rc = ensure(c, &c->d_cyl, &c->cyl_cap, c->h_cyl.size());
+    if (rc) return rc;
+    if (M > 0)
+        HIPCHK(c, hipMemcpyAsync(c->d_cyl, c->h_cyl.data(), c->h_cyl.size() * sizeof(Cyl), hipMemcpyHostToDevice, c->stream));
+
+    const int nblocks = impl == WV_IMPL_STAGED ? staged_energy_blocks(c->grid) : fused_energy_blocks(c->fused);
+    const int init_blocks = nblocks;  // the initial state's partials use the same row width
+    if (want_signal) {
+        rc = ensure(c, &c->d_epart, &c->epart_cap, (size_t)(nsteps + 1) * nblocks * 3);
+        if (rc) return rc;
+        rc = ensure(c, &c->d_signal, &c->signal_cap, (size_t)(nsteps + 1) * 3);
+        if (rc) return rc;
+    }
+    if (want_fields) {
+        rc = ensure(c, &c->d_traj, &c->traj_cap, (size_t)2 * (nsteps + 1) * c->P);
+        if (rc) return rc;
+    }
+    if (c->profiling) {
+        while (c->kev.size() < 2 * (size_t)nsteps) {
+            hipEvent_t ev;
+            HIPCHK(c, hipEventCreate(&ev));
+            c->kev.push_back(ev);
+        }
+    }
+    if (impl == WV_IMPL_FUSED) {
+        rc = fused_prepare(c->fused, frame(c, 2), c->d_cyl, M > 0 ? c->h_cyl.data() : nullptr, M, 3 * nsteps, c->stream);
+        if (rc) return fail(c, WV_ERR_HIP, "fused_prepare failed");
+    }
+
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipEventRecord(c->ev0, st));
+
+    float *tt = want_fields ? c->d_traj : nullptr;                               // u_tot planes
+    float *ti_ = want_fields ? c->d_traj + (size_t)(nsteps + 1) * c->P : nullptr;  // u_inc planes
+
+    float *cur = frame(c, 2);
+    if (want_signal) {
+        if (init_blocks > 0) HIPCHK(c, hipMemsetAsync(c->d_epart, 0, (size_t)nblocks * 3 * sizeof(float), st));
+        launch_energy_partial(c->grid, cur, c->d_epart, nblocks, st);
+    }
+    if (want_fields) launch_copy_planes(cur, c->P, tt, ti_, st);
+    if (capture && nsteps == 2 * WV_FRAMESKIP)
+        HIPCHK(c, hipMemcpyAsync(frame(c, 0), cur, c->N * sizeof(float), hipMemcpyDeviceToDevice, st));
+
+    for (int s = 1; s <= nsteps; ++s) {
+        float *out;
+        if (capture && s == nsteps - 2 * WV_FRAMESKIP) out = frame(c, 0);
+        else if (capture && s == nsteps - WV_FRAMESKIP) out = frame(c, 1);
+        else if (s == nsteps) out = frame(c, 2);
+        else out = (cur == c->d_scratch[0]) ? c->d_scratch[1] : c->d_scratch[0];
+        if (out == cur) {  // nsteps == 1: the step would read and write the last frame
+            HIPCHK(c, hipMemcpyAsync(c->d_scratch[0], cur, c->N * sizeof(float), hipMemcpyDeviceToDevice, st));
+            cur = c->d_scratch[0];
+        }
+        const Cyl *cyl_s = c->d_cyl + (size_t)(3 * (s - 1)) * (M > 0 ? M : 0);
+        const float *sf = c->h_sfac.data() + 3 * (size_t)(s - 1);
+        float *ep = want_signal ? c->d_epart + (size_t)s * nblocks * 3 : nullptr;
+        float *tts = tt ? tt + (size_t)s * c->P : nullptr;
+        float *tis = ti_ ? ti_ + (size_t)s * c->P : nullptr;
+        const float *G = c->has_source ? c->d_G : nullptr;
+        if (c->profiling) HIPCHK(c, hipEventRecord(c->kev[2 * (s - 1)], st));
+        if (impl == WV_IMPL_STAGED) {
+            StageIO io{};
+            io.u = cur;
+            io.acc = c->d_acc;
+            io.G = G;
+            io.M = M;
+            io.dt = dt;
+            // k1
+            io.yin = cur; io.out = c->d_yA; io.sfac = sf[0]; io.cyl = cyl_s; io.a = hdt;
+            launch_stage(c->grid, io, 0, st);
+            // k2
+            io.yin = c->d_yA; io.out = c->d_yB; io.sfac = sf[1]; io.cyl = cyl_s + M; io.a = hdt;
+            launch_stage(c->grid, io, 1, st);
+            // k3
+            io.yin = c->d_yB; io.out = c->d_yA; io.sfac = sf[1]; io.cyl = cyl_s + M; io.a = dt;
+            launch_stage(c->grid, io, 2, st);
+            // k4 + update + energies
+            io.yin = c->d_yA; io.out = out; io.sfac = sf[2]; io.cyl = cyl_s + 2 * M; io.a = dt;
+            io.epart = ep; io.traj_tot = tts; io.traj_inc = tis;
+            launch_stage(c->grid, io, 3, st);
+        } else {
+            FusedStep fs{};
+            fs.u = cur;
+            fs.out = out;
+            fs.G = G;
+            fs.sfac[0] = sf[0]; fs.sfac[1] = sf[1]; fs.sfac[2] = sf[2];
+            fs.table_row = 3 * (s - 1);
+            fs.dt = dt;
+            fs.epart = ep;
+            fs.traj_tot = tts;
+            fs.traj_inc = tis;
+            fused_launch(c->fused, fs, st);
+        }
+        if (c->profiling) HIPCHK(c, hipEventRecord(c->kev[2 * (s - 1) + 1], st));
+        cur = out;
+    }
+    HIPCHK(c, hipGetLastError());
+    if (want_signal) launch_energy_final(c->d_epart, nsteps + 1, nblocks, c->dOmega, c->d_signal, st);
+    HIPCHK(c, hipEventRecord(c->ev1, st));
+    HIPCHK(c, hipGetLastError());
+
+    c->pending = true;
+    c->pend_nsteps = nsteps;
+    c->pend_signal = want_signal != 0;
+    c->pend_fields = want_fields != 0;
+    c->timing = wv_timing{};
+    c->timing.steps = nsteps;
+    c->timing.impl = impl;
+    return WV_OK;
+}
+
+int wv_integrate_end(wv_ctx *c, float *signal, float *u_tot, float *u_inc)
+{
+    CHECK_CTX(c);
+    if (!c->pending) return fail(c, WV_ERR_STATE, "wv_integrate_end: no integrate pending");
+    c->pending = false;
+    const int n = c->pend_nsteps;
+    if (signal && !c->pend_signal) return fail(c, WV_ERR_STATE, "wv_integrate_end: signal was not requested in _begin");
+    if ((u_tot || u_inc) && !c->pend_fields) return fail(c, WV_ERR_STATE, "wv_integrate_end: fields were not requested in _begin");
+    hipStream_t st = c->stream;
+    if (signal) HIPCHK(c, hipMemcpyAsync(signal, c->d_signal, (size_t)(n + 1) * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (u_tot) HIPCHK(c, hipMemcpyAsync(u_tot, c->d_traj, (size_t)(n + 1) * c->P * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (u_inc)
+        HIPCHK(c, hipMemcpyAsync(u_inc, c->d_traj + (size_t)(n + 1) * c->P, (size_t)(n + 1) * c->P * sizeof(float),
+                                 hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    float ms = 0.0f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->timing.total_ms = ms;
+    if (c->profiling) {
+        double sum = 0.0;
+        for (int s = 0; s < n; ++s) {
+            float k = 0.0f;
+            HIPCHK(c, hipEventElapsedTime(&k, c->kev[2 * s], c->kev[2 * s + 1]));
+            sum += k;
+        }
+        c->timing.step_kernel_ms = sum;
+        c->timing.step_kernel_launches = n * (c->timing.impl == WV_IMPL_STAGED ? 4 : 1);
+    }
+    return WV_OK;
+}
+
+int wv_integrate(wv_ctx *c, const float *tspan, int nsteps, int capture, float *signal, float *u_tot, float *u_inc)
+{
+    int rc = wv_integrate_begin(c, tspan, nsteps, capture, signal != nullptr, (u_tot || u_inc) ? 1 : 0);
+    if (rc) return rc;
+    return wv_integrate_end(c, signal, u_tot, u_inc);
+}
+
+int wv_set_profiling(wv_ctx *c, int on)
+{
+    CHECK_CTX(c);
+    c->profiling = on != 0;
+    return WV_OK;
+}
+
+int wv_get_timing(wv_ctx *c, wv_timing *out)
+{
+    CHECK_CTX(c);
+    if (!out) return fail(c, WV_ERR_INVALID, "wv_get_timing: NULL");
+    *out = c->timing;
+    return WV_OK;
+}
+
+int wv_set_stream(wv_ctx *c, void *hip_stream)
+{
+    CHECK_CTX(c);
+    if (c->pending) return fail(c, WV_ERR_STATE, "wv_set_stream: an integrate is pending");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return WV_OK;
+}
+
+int wv_synchronize(wv_ctx *c)
+{
+    CHECK_CTX(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WV_OK;
+}
+
+int wv_device_frames(wv_ctx *c, void **dptr, size_t *bytes)
+{
+    CHECK_CTX(c);
+    if (!dptr) return fail(c, WV_ERR_INVALID, "wv_device_frames: NULL");
+    *dptr = c->d_frames;
+    if (bytes) *bytes = 3 * c->N * sizeof(float);
+    return WV_OK;
+}
+
+int wv_device_source_shape(wv_ctx *c, void **dptr, size_t *bytes)
+{
+    CHECK_CTX(c);
+    if (!dptr) return fail(c, WV_ERR_INVALID, "wv_device_source_shape: NULL");
+    *dptr = c->d_G;
+    if (bytes) *bytes = c->P * sizeof(float);
+    return WV_OK;
+}
+
+}  // extern "C"

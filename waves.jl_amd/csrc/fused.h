@@ -1,0 +1,34 @@
+// Host-side interface of the fused Runge-Kutta step kernel (kernels_fused.hip): all four stages of one
+// integration step (src/dynamics.jl:9-16 around src/dynamics.jl:151-188) in ONE launch.
+#pragma once
+#include "kernels.h"
+
+namespace wv {
+
+struct FusedPlan;
+
+struct FusedStep {
+    const float *u;     // state at the start of the step (12 planes)
+    float *out;         // state at the end of the step (12 planes, != u)
+    const float *G;     // source shape or nullptr
+    float sfac[3];      // source time factor at t, t + dt/2, t + dt
+    int table_row;      // row of the cylinder table holding stage time t (rows +1, +2: t + dt/2, t + dt)
+    float dt;
+    float *epart;       // per-block energy partials [fused_energy_blocks][3] or nullptr
+    float *traj_tot;    // optional copies of the new U_tot / U_inc planes
+    float *traj_inc;
+};
+
+FusedPlan *fused_create(const Grid &g, const float *sx_host, const float *sy_host);
+void fused_destroy(FusedPlan *p);
+void fused_set_pml(FusedPlan *p, const float *sx_host, const float *sy_host);
+// The caller replaced the state: the "auxiliary fields are zero outside the PML" fast-path precondition is unknown.
+void fused_state_changed(FusedPlan *p);
+void fused_state_zeroed(FusedPlan *p);
+int fused_energy_blocks(const FusedPlan *p);
+// Called once per wv_integrate before the first step: d_table = device cylinder table (rows x M), h_table its host copy.
+int fused_prepare(FusedPlan *p, const float *state, const Cyl *d_table, const Cyl *h_table, int M, int rows,
+                  hipStream_t s);
+void fused_launch(FusedPlan *p, const FusedStep &st, hipStream_t s);
+
+}  // namespace wv

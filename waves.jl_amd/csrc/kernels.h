@@ -1,0 +1,51 @@
+// Launch wrappers of the HIP kernels (implemented in kernels_staged.hip / kernels_aux.hip / kernels_fused.hip).
+#pragma once
+#include "common.h"
+
+namespace wv {
+
+// Everything a Runge-Kutta stage needs that does not change during one wv_integrate call.
+struct Grid {
+    int nx, ny;
+    size_t P;          // nx*ny
+    Ops ops;
+    const float *x;    // device, nx
+    const float *y;    // device, ny
+    const float *sx;   // device, nx   sigma_x profile (src/pml.jl:21-29)
+    const float *sy;   // device, ny   sigma_y = sigma_x' (src/dynamics.jl:161-162)
+    float c0;
+    float c0sq;        // dyn.c0 .^ 2 (scalar b of the incident set, src/dynamics.jl:159,186)
+};
+
+struct StageIO {
+    const float *yin;  // stage input (12 planes)
+    const float *u;    // state at the start of the step (12 planes)
+    float *acc;        // running k1 + 2k2 + 2k3 (12 planes)
+    float *out;        // next stage input (stages 0..2), new state (stage 3) or k (RHS only)
+    const float *G;    // source shape or nullptr (NoSource)
+    float sfac;        // sin(2f0*pi*t*freq) for this stage time
+    const Cyl *cyl;    // M cylinders at this stage time (device) or nullptr
+    int M;
+    float a;           // 0.5f0*dt (stages 0,1) or dt (stage 2)
+    float dt;
+    float *epart;      // stage 3: per-block energy partials [nblocks][3] or nullptr
+    float *traj_tot;   // stage 3: optional copy of U_tot / U_inc planes
+    float *traj_inc;
+};
+
+// stage: 0..3 = RK stages of src/dynamics.jl:9-16; 4 = RHS only (out = k).
+void launch_stage(const Grid &g, const StageIO &io, int stage, hipStream_t s);
+int staged_energy_blocks(const Grid &g);
+
+// aux kernels
+void launch_energy_partial(const Grid &g, const float *state, float *epart, int nblocks, hipStream_t s);
+// signal[r][c] = float(sum_b epart[r][b][c]) * dOmega for r in [0, nrows)
+void launch_energy_final(const float *epart, int nrows, int nblocks, float dOmega, float *signal, hipStream_t s);
+void launch_speed_field(const Grid &g, const Cyl *cyl, int M, float *out, hipStream_t s);
+void launch_gaussian(const Grid &g, int K, const float *mu, const float *sigma, const float *a, float *out,
+                     hipStream_t s);
+void launch_scale(const float *in, float f, float *out, size_t n, hipStream_t s);
+void launch_gradient(const Grid &g, int axis, const float *u, float *out, hipStream_t s);
+void launch_copy_planes(const float *state, size_t P, float *tot, float *inc, hipStream_t s);
+
+}  // namespace wv

@@ -1,0 +1,166 @@
+// Small kernels around the integrator: energy reductions (K5), the wave-speed field (K1) and Gaussian source shape
+// (K2) as stand-alone passes, the gradient operator, plane copies.  All are single-pass, HBM-bound, coalesced along x.
+#include "kernels.h"
+
+namespace wv {
+
+namespace {
+
+constexpr int TPB = 256;
+
+// [sum U_tot^2, sum U_inc^2, sum (U_tot-U_inc)^2] per block.  src/env.jl:105-111 (squares and difference in fp32).
+__global__ __launch_bounds__(TPB) void k_energy_partial(const float *__restrict__ ut, const float *__restrict__ ui,
+                                                        size_t P, float *__restrict__ epart)
+{
+    float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f;
+    for (size_t q = (size_t)blockIdx.x * TPB + threadIdx.x; q < P; q += (size_t)gridDim.x * TPB) {
+        const float t = ut[q], i = ui[q], s = t - i;
+        e0 += t * t;
+        e1 += i * i;
+        e2 += s * s;
+    }
+    __shared__ float red[3][TPB / kWave];
+    e0 = wave_sum(e0);
+    e1 = wave_sum(e1);
+    e2 = wave_sum(e2);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[0][w] = e0;
+        red[1][w] = e1;
+        red[2][w] = e2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            epart[(size_t)blockIdx.x * 3 + c] = (red[c][0] + red[c][1]) + (red[c][2] + red[c][3]);
+    }
+}
+
+// Deterministic second pass: one block per saved time point sums that point's per-block partials in double, in a
+// fixed order, rounds once to fp32 and applies `* dOmega` in fp32 (src/env.jl:108-111).
+__global__ __launch_bounds__(TPB) void k_energy_final(const float *__restrict__ epart, int nblocks, float dOmega,
+                                                      float *__restrict__ signal)
+{
+    const int r = blockIdx.x;
+    const float *p = epart + (size_t)r * nblocks * 3;
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += TPB) {
+        s[0] += (double)p[b * 3 + 0];
+        s[1] += (double)p[b * 3 + 1];
+        s[2] += (double)p[b * 3 + 2];
+    }
+    __shared__ double red[3][TPB];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) red[c][threadIdx.x] = s[c];
+    __syncthreads();
+    for (int off = TPB / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) signal[r * 3 + threadIdx.x] = (float)red[threadIdx.x][0] * dOmega;
+}
+
+// speed(design, grid, c0): src/designs.jl:110-116.
+__global__ __launch_bounds__(TPB) void k_speed_field(Grid g, const Cyl *__restrict__ cyl, int M, float *__restrict__ out)
+{
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i < g.nx && j < g.ny) out[(size_t)j * g.nx + i] = speed_at(g.x[i], g.y[j], cyl, M, g.c0);
+}
+
+// build_normal(grid, mu, sigma, a): src/utils.jl:12-18.  exp is evaluated in double and rounded once (Julia's
+// exp(::Float32) is accurate to < 1 ulp); everything else is fp32 in the reference's order.
+__global__ __launch_bounds__(TPB) void k_gaussian(Grid g, int K, const float *__restrict__ mu,
+                                                  const float *__restrict__ sigma, const float *__restrict__ a,
+                                                  float *__restrict__ out)
+{
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= g.nx || j >= g.ny) return;
+    const float x = g.x[i], y = g.y[j];
+    const float two_pi = 6.2831855f;  // 2.0f0 * pi in Float32
+    float acc = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        const float ddx = x - mu[k];      // mu is K x 2 column-major
+        const float ddy = y - mu[K + k];
+        const float d2 = ddx * ddx + ddy * ddy;
+        const float s2 = sigma[k] * sigma[k];
+        const float coef = 1.0f / (two_pi * s2);
+        const float e = (float)exp((double)((-d2) / (2.0f * s2)));
+        acc = acc + (coef * a[k]) * e;
+    }
+    out[(size_t)j * g.nx + i] = acc;
+}
+
+__global__ __launch_bounds__(TPB) void k_scale(const float *__restrict__ in, float f, float *__restrict__ out, size_t n)
+{
+    for (size_t q = (size_t)blockIdx.x * TPB + threadIdx.x; q < n; q += (size_t)gridDim.x * TPB) out[q] = in[q] * f;
+}
+
+__global__ __launch_bounds__(TPB) void k_gradient(Grid g, int axis, const float *__restrict__ u, float *__restrict__ out)
+{
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= g.nx || j >= g.ny) return;
+    float d;
+    if (axis == 0)
+        d = deriv(g.ops, i, g.nx, [&](int ii) { return u[(size_t)j * g.nx + ii]; });
+    else
+        d = deriv(g.ops, j, g.ny, [&](int jj) { return u[(size_t)jj * g.nx + i]; });
+    out[(size_t)j * g.nx + i] = d;
+}
+
+__global__ __launch_bounds__(TPB) void k_copy_planes(const float *__restrict__ state, size_t P, float *__restrict__ tot,
+                                                     float *__restrict__ inc)
+{
+    for (size_t q = (size_t)blockIdx.x * TPB + threadIdx.x; q < P; q += (size_t)gridDim.x * TPB) {
+        if (tot) tot[q] = state[q];
+        if (inc) inc[q] = state[6 * P + q];
+    }
+}
+
+dim3 grid2d(const Grid &g) { return dim3((g.nx + 63) / 64, (g.ny + 3) / 4, 1); }
+int grid1d(size_t n) { size_t b = (n + TPB - 1) / TPB; return (int)(b > 2048 ? 2048 : (b ? b : 1)); }
+
+}  // namespace
+
+void launch_energy_partial(const Grid &g, const float *state, float *epart, int nblocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_energy_partial, dim3(nblocks), dim3(TPB), 0, s, state, state + 6 * g.P, g.P, epart);
+}
+
+void launch_energy_final(const float *epart, int nrows, int nblocks, float dOmega, float *signal, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_energy_final, dim3(nrows), dim3(TPB), 0, s, epart, nblocks, dOmega, signal);
+}
+
+void launch_speed_field(const Grid &g, const Cyl *cyl, int M, float *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_speed_field, grid2d(g), dim3(TPB), 0, s, g, cyl, M, out);
+}
+
+void launch_gaussian(const Grid &g, int K, const float *mu, const float *sigma, const float *a, float *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_gaussian, grid2d(g), dim3(TPB), 0, s, g, K, mu, sigma, a, out);
+}
+
+void launch_scale(const float *in, float f, float *out, size_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_scale, dim3(grid1d(n)), dim3(TPB), 0, s, in, f, out, n);
+}
+
+void launch_gradient(const Grid &g, int axis, const float *u, float *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_gradient, grid2d(g), dim3(TPB), 0, s, g, axis, u, out);
+}
+
+void launch_copy_planes(const float *state, size_t P, float *tot, float *inc, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_copy_planes, dim3(grid1d(P)), dim3(TPB), 0, s, state, P, tot, inc);
+}
+
+}  // namespace wv

@@ -1,0 +1,141 @@
+"""WaveEnv -- host mirror of the reference's src/env.jl: the RL "gym" around the device integrator."""
+from __future__ import annotations
+
+import numpy as np
+
+from .designs import DesignInterpolator, DesignSpace, WATER, build_action_space, rand
+from .dims import TwoDim, get_dx, get_dy
+from .dynamics import AcousticDynamics, Integrator, build_tspan, runge_kutta
+from .sources import NoSource
+
+f32 = np.float32
+FRAMESKIP = 10  # src/env.jl:90
+
+
+class WaveEnvState:
+    """src/env.jl:5-12."""
+
+    def __init__(self, dim, tspan, wave, design):
+        self.dim, self.tspan, self.wave, self.design = dim, tspan, wave, design
+
+
+class WaveEnv:
+    """src/env.jl:14-67.  Same constructor keywords and defaults; `device`, `impl` and `rng` are additions
+    (device replaces `Flux.device!(n)`; rng replaces Julia's global RNG)."""
+
+    def __init__(self, dim: TwoDim, *, design_space: DesignSpace, action_speed=250.0, source=None, c0=WATER,
+                 pml_width=2.0, pml_scale=20000.0, resolution=(128, 128), dt=1e-5, integration_steps=100, actions=10,
+                 device=0, impl="auto", rng=None, return_fields=True):
+        if not all(s > r for s, r in zip(dim.size(), resolution)):  # src/env.jl:52
+            raise AssertionError("Resolution must be less than finite element grid.")
+        self.rng = rng if rng is not None else np.random.default_rng()
+        self.dim = dim
+        self.design_space = design_space
+        self.design = rand(design_space, self.rng)                      # :55
+        self.source = source if source is not None else NoSource()
+        dyn = AcousticDynamics(dim, c0, pml_width, pml_scale, device=device, impl=impl)   # :58
+        self.iter = Integrator(runge_kutta, dyn, dt)                    # :59
+        self.ctx = self.iter.ctx                                        # env.wave lives on the device: zeros(nx,ny,12,3)
+        self.source.attach(self.ctx)
+        self.signal = np.zeros(integration_steps + 1, dtype=np.float32)  # :56
+        self.time_step = 0
+        self.resolution = tuple(resolution)
+        self.action_speed = f32(action_speed)
+        self.dt = f32(dt)
+        self.integration_steps = int(integration_steps)
+        self.actions = int(actions)
+        self.return_fields = return_fields
+
+    # --- src/env.jl:69-79
+    def time(self):
+        return f32(f32(self.time_step) * self.dt)
+
+    def build_tspan(self):
+        return build_tspan(self.time(), self.dt, self.integration_steps)
+
+    def is_terminated(self):
+        return self.time_step >= self.actions * self.integration_steps
+
+    @property
+    def wave(self):
+        """env.wave (nx, ny, 12, 3), downloaded from the device."""
+        return self.ctx.get_frames()
+
+    @wave.setter
+    def wave(self, w):
+        self.ctx.set_frames(w)
+
+    def reset(self):
+        """RLBase.reset!  src/env.jl:81-88."""
+        self.time_step = 0
+        self.ctx.reset()                                    # env.wave *= 0f0
+        self.design = rand(self.design_space, self.rng)
+        self.signal = self.signal * f32(0.0)
+        self.source.reset(self.rng)
+        return None
+
+    def __call__(self, action):
+        """(env::WaveEnv)(action)  src/env.jl:91-121."""
+        tspan = self.build_tspan()
+        ti = self.time()
+        current_design = self.design
+        next_design = self.design_space(current_design, action)
+        interp = DesignInterpolator(current_design, next_design, ti, tspan[-1])
+        if self.integration_steps < 2 * FRAMESKIP:
+            raise IndexError("BoundsError: sol[:, :, :, end-20:10:end] needs integration_steps >= 20 (src/env.jl:116)")
+        self.ctx.set_design(*interp.abi_args())             # C = t -> speed(interp(t), grid, c0)
+        sig, u_tot, u_inc = self.ctx.integrate(tspan, capture_frames=True, want_signal=True,
+                                               want_fields=self.return_fields)
+        self.signal = sig                                   # hcat(tot_energy, inc_energy, sc_energy)
+        self.design = next_design
+        self.time_step += self.integration_steps
+        return tspan, interp, u_tot, u_inc
+
+    def state(self):
+        """RLBase.state  src/env.jl:132-137 WITHOUT the imresize (Images.jl's interpolation is third-party and
+        unpinned: SURVEY 8f rank 1, a "next" row).  Returns the three U_tot frames + source shape at full resolution."""
+        w = self.ctx.get_frames()[:, :, 0, :]
+        shape = self.ctx.source_shape()
+        x = np.concatenate([w, shape[:, :, None]], axis=2)
+        return WaveEnvState(self.dim, self.build_tspan(), x, self.design)
+
+    def action_space(self):
+        """RLBase.action_space  src/env.jl:143-145."""
+        scale = f32(f32(self.action_speed * self.dt) * f32(self.integration_steps))
+        return build_action_space(rand(self.design_space, self.rng), scale)
+
+    def reward(self):
+        """RLBase.reward  src/env.jl:147-149."""
+        return np.sum(self.signal)
+
+
+# RLBase-style free functions, as the reference's scripts call them
+def reset(env):
+    return env.reset()
+
+
+def is_terminated(env):
+    return env.is_terminated()
+
+
+def state(env):
+    return env.state()
+
+
+def action_space(env):
+    return env.action_space()
+
+
+def reward(env):
+    return env.reward()
+
+
+class RandomDesignPolicy:
+    """src/env.jl:151-157."""
+
+    def __init__(self, a_space: DesignSpace, rng=None):
+        self.a_space = a_space
+        self.rng = rng if rng is not None else np.random.default_rng()
+
+    def __call__(self, env):
+        return rand(self.a_space, self.rng)
