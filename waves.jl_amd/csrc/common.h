@@ -4,25 +4,10 @@
 // (x-px)^2+(y-py)^2 < r^2 flips cells on 1-ulp differences (hard part 2).
 #pragma once
 #include <hip/hip_runtime.h>
-#include <stddef.h>
-#include <stdint.h>
+
+#include "types.h"
 
 namespace wv {
-
-constexpr int kFields = 12;  // src/dynamics.jl:185-187
-constexpr int kWave = 64;    // CDNA wavefront
-
-// Non-zeros of gradient(x) (src/operators.jl:10-22), each one coef/(2*Delta) rounded on its own.
-struct Ops {
-    float cm, cp;      // row i:   -1/(2D) at i-1, +1/(2D) at i+1
-    float f0, f1, f2;  // row 0:   [-3, 4, -1]/(2D) at 0, 1, 2
-    float b0, b1, b2;  // row n-1: [ 1,-4,  3]/(2D) at n-3, n-2, n-1
-};
-
-// One cylinder at one stage time: centre, r*r and wave speed (src/designs.jl:99-116).
-struct Cyl {
-    float px, py, r2, c;
-};
 
 // `grad * u` for one output element (src/operators.jl:45-46): SparseArrays accumulates the row's
 // non-zeros in ascending column order from zero, each product rounded separately.
