@@ -301,7 +301,7 @@ int wv_create(const wv_config *cfg, const float *x, const float *y, wv_ctx **out
     g.c0 = cfg->c0;
     g.c0sq = cfg->c0 * cfg->c0;
 
-    c->fused = fused_create(g, c->sx.data(), c->sy.data());
+    c->fused = fused_create(g, c->x.data(), c->y.data(), c->sx.data(), c->sy.data());
     if (!c->fused) {
         wv_destroy(c);
         return fail(nullptr, WV_ERR_HIP, "wv_create: fused plan allocation failed");
@@ -544,7 +544,7 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     const int M = c->M;
     const float dt = c->cfg.dt;
     const float hdt = 0.5f * dt;
-    const int impl = c->cfg.impl == WV_IMPL_FUSED ? WV_IMPL_FUSED : WV_IMPL_STAGED;  // AUTO -> staged until the fused kernel is verified
+    const int impl = c->cfg.impl == WV_IMPL_STAGED ? WV_IMPL_STAGED : WV_IMPL_FUSED;  // AUTO -> fused
 
     // per-stage coefficient tables: stage times t, t + 0.5f0*dt, t + dt (src/dynamics.jl:10-13)
     c->h_sfac.assign(3 * (size_t)nsteps, 0.0f);
@@ -582,7 +582,8 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
         }
     }
     if (impl == WV_IMPL_FUSED) {
-        rc = fused_prepare(c->fused, frame(c, 2), c->d_cyl, M > 0 ? c->h_cyl.data() : nullptr, M, 3 * nsteps, c->stream);
+        rc = fused_prepare(c->fused, c->d_frames, c->d_scratch[0], c->d_scratch[1], capture != 0, c->d_cyl,
+                           M > 0 ? c->h_cyl.data() : nullptr, M, 3 * nsteps, c->stream);
         if (rc) return fail(c, WV_ERR_HIP, "fused_prepare failed");
     }
 

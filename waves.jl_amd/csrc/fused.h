@@ -19,16 +19,19 @@ struct FusedStep {
     float *traj_inc;
 };
 
-FusedPlan *fused_create(const Grid &g, const float *sx_host, const float *sy_host);
+FusedPlan *fused_create(const Grid &g, const float *x_host, const float *y_host, const float *sx_host,
+                        const float *sy_host);
 void fused_destroy(FusedPlan *p);
 void fused_set_pml(FusedPlan *p, const float *sx_host, const float *sy_host);
 // The caller replaced the state: the "auxiliary fields are zero outside the PML" fast-path precondition is unknown.
 void fused_state_changed(FusedPlan *p);
 void fused_state_zeroed(FusedPlan *p);
-int fused_energy_blocks(const FusedPlan *p);
+int fused_energy_blocks(FusedPlan *p);
 // Called once per wv_integrate before the first step: d_table = device cylinder table (rows x M), h_table its host copy.
-int fused_prepare(FusedPlan *p, const float *state, const Cyl *d_table, const Cyl *h_table, int M, int rows,
-                  hipStream_t s);
+// frames = env.wave (3 states, the last one is the initial condition), scratch0/1 the two ping-pong states.
+int fused_prepare(FusedPlan *p, float *frames, float *scratch0, float *scratch1, bool capture, const Cyl *d_table,
+                  const Cyl *h_table, int M, int rows, hipStream_t s);
 void fused_launch(FusedPlan *p, const FusedStep &st, hipStream_t s);
+void fused_variant_counts(const FusedPlan *p, int out[3]);  // tiles per variant: FAST, MID, GEN
 
 }  // namespace wv
