@@ -25,11 +25,13 @@ int wo_integrate(int nx, int ny, const float *x, const float *y, const float *sx
 
 using namespace wv;
 
+static F2 g_lds_raw[lds_elems(8 * 6)];  // deliberately NOT cleared between tiles: stale contents must never matter
+
 template <bool PML, bool EDGE, int NW, int RPT>
 static void run_tile(const FusedParams &p, const TileDesc &t, double esum[3])
 {
     constexpr int NT = NW * 64;
-    static FusedLds<NW * RPT> lds;  // deliberately NOT cleared between tiles: stale contents must never matter
+    const FusedLds lds = lds_view(g_lds_raw, NW * RPT);
     std::vector<FusedRegs<PML, RPT>> regs(NT);
     for (int tid = 0; tid < NT; ++tid) fused_load<PML, EDGE, NW, RPT>(p, t, tid, regs[tid]);
 #define STAGE(S)                                                                                            \
@@ -44,14 +46,14 @@ static void run_tile(const FusedParams &p, const TileDesc &t, double esum[3])
     }
 }
 
-template <int NW, int RPT>
+template <int NW, int RF, int RP>
 static void run_step(const FusedParams &p, const HostPlan &pl, double esum[3])
 {
     for (const TileDesc &t : pl.tiles) {
         switch (t.variant) {
-            case VAR_FAST: run_tile<false, false, NW, RPT>(p, t, esum); break;
-            case VAR_MID: run_tile<true, false, NW, RPT>(p, t, esum); break;
-            default: run_tile<true, true, NW, RPT>(p, t, esum); break;
+            case VAR_FAST: run_tile<false, false, NW, RF>(p, t, esum); break;
+            case VAR_MID: run_tile<true, false, NW, RP>(p, t, esum); break;
+            default: run_tile<true, true, NW, RP>(p, t, esum); break;
         }
     }
 }
@@ -69,12 +71,12 @@ struct Case {
     const char *name;
     int n;
     int nsteps;
-    int NW, RPT;
+    int NW, RF, RP;  // waves per block; rows per thread of FAST / MID+GEN tiles
     float pml_width, pml_scale;
     int M;           // cylinders
     int source;      // 0/1
     int aux;         // 1: random non-zero auxiliary fields everywhere (forces MID tiles); 0: aux zero -> FAST tiles
-    int force_all;   // 1: non-monotonic trick disabled; kept for symmetry
+    int force_all;   // 1: natural launch order instead of the XCD-aware one
 };
 
 static int run_case(const Case &cs)
@@ -148,7 +150,8 @@ static int run_case(const Case &cs)
         }
     }
     HostPlan pl;
-    if (!plan_build_tiles(pl, n, n, cs.NW * cs.RPT, x.data(), x.data(), sx.data(), sx.data(), cs.aux == 0)) {
+    if (!plan_build_tiles(pl, n, n, cs.NW * cs.RF, cs.NW * cs.RP, x.data(), x.data(), sx.data(), sx.data(), cs.aux == 0,
+                          cs.force_all == 0)) {
         printf("%-28s plan_build_tiles failed\n", cs.name);
         return 1;
     }
@@ -175,12 +178,14 @@ static int run_case(const Case &cs)
         p.tiles = pl.tiles.data(); p.cyl_idx = idx.data();
         p.epart = nullptr; p.traj_tot = nullptr; p.traj_inc = nullptr;
         double es[3] = {0, 0, 0};
-        if (cs.NW == 8 && cs.RPT == 2) run_step<8, 2>(p, pl, es);
-        else if (cs.NW == 8 && cs.RPT == 3) run_step<8, 3>(p, pl, es);
-        else if (cs.NW == 8 && cs.RPT == 4) run_step<8, 4>(p, pl, es);
-        else if (cs.NW == 4 && cs.RPT == 4) run_step<4, 4>(p, pl, es);
-        else if (cs.NW == 4 && cs.RPT == 6) run_step<4, 6>(p, pl, es);
-        else { printf("unsupported NW/RPT\n"); return 1; }
+        const int key = cs.NW * 100 + cs.RF * 10 + cs.RP;
+        if (key == 842) run_step<8, 4, 2>(p, pl, es);
+        else if (key == 832) run_step<8, 3, 2>(p, pl, es);
+        else if (key == 833) run_step<8, 3, 3>(p, pl, es);
+        else if (key == 822) run_step<8, 2, 2>(p, pl, es);
+        else if (key == 844) run_step<8, 4, 4>(p, pl, es);
+        else if (key == 464) run_step<4, 6, 4>(p, pl, es);
+        else { printf("unsupported NW/RF/RP\n"); return 1; }
         for (int c = 0; c < 3; ++c) {
             const double r = eref[3 * (size_t)(s + 1) + c];
             const double rel = fabs(es[c] - r) / (fabs(eref[3 * (size_t)(s + 1)]) + 1e-300);
@@ -197,8 +202,8 @@ static int run_case(const Case &cs)
         }
     double umax = 0;
     for (size_t q = 0; q < P; ++q) umax = fmax(umax, fabs(ref[q]));
-    printf("%-28s n=%4d steps=%3d NWxRPT=%dx%d tiles FAST/MID/GEN=%d/%d/%d  culled-list=%zu  max|U|=%.3g  energy rel=%.1e  %s",
-           cs.name, n, nsteps, cs.NW, cs.RPT, pl.count[0], pl.count[1], pl.count[2], idx.size(), umax, emax,
+    printf("%-28s n=%4d steps=%3d NW,RF,RP=%d,%d,%d tiles FAST/MID/GEN=%d/%d/%d  culled-list=%zu  max|U|=%.3g  energy rel=%.1e  %s",
+           cs.name, n, nsteps, cs.NW, cs.RF, cs.RP, pl.count[0], pl.count[1], pl.count[2], idx.size(), umax, emax,
            bad ? "MISMATCH" : "bit-exact\n");
     if (bad) {
         const size_t f = first / P, q = first % P;
@@ -211,20 +216,22 @@ int main(int argc, char **argv)
 {
     const bool quick = argc > 1 && !strcmp(argv[1], "quick");
     std::vector<Case> cases = {
-        {"fast+pml+edge, design+src", 160, 6, 8, 3, 2.0f, 20000.0f, 6, 1, 0, 0},
-        {"all-mid (aux everywhere)", 96, 5, 8, 3, 2.0f, 20000.0f, 4, 1, 1, 0},
-        {"no pml (scale 0), no design", 130, 5, 8, 3, 1.0f, 0.0f, 0, 1, 0, 0},
-        {"RPT=2 small tiles", 131, 4, 8, 2, 2.0f, 20000.0f, 5, 1, 0, 0},
-        {"RPT=4 tall tiles", 200, 4, 8, 4, 2.0f, 20000.0f, 5, 0, 0, 0},
-        {"NW=4 RPT=6", 150, 4, 4, 6, 2.0f, 20000.0f, 3, 1, 0, 0},
-        {"NW=4 RPT=4", 117, 4, 4, 4, 3.0f, 20000.0f, 3, 1, 1, 0},
-        {"tiny grid 8", 8, 3, 8, 3, 2.0f, 20000.0f, 1, 1, 0, 0},
-        {"grid 57 (two strips)", 57, 4, 8, 3, 2.0f, 20000.0f, 2, 1, 0, 0},
-        {"many cylinders", 180, 3, 8, 3, 2.0f, 20000.0f, 40, 1, 0, 0},
+        {"default tiles, design+src", 160, 6, 8, 4, 2, 2.0f, 20000.0f, 6, 1, 0, 0},
+        {"all-mid (aux everywhere)", 96, 5, 8, 4, 2, 2.0f, 20000.0f, 4, 1, 1, 0},
+        {"aux everywhere, 260", 260, 3, 8, 4, 2, 2.0f, 20000.0f, 4, 1, 1, 0},
+        {"no pml (scale 0), no design", 130, 5, 8, 4, 2, 1.0f, 0.0f, 0, 1, 0, 0},
+        {"RF,RP=3,2", 231, 4, 8, 3, 2, 2.0f, 20000.0f, 5, 1, 0, 0},
+        {"RF,RP=3,3 natural order", 200, 4, 8, 3, 3, 2.0f, 20000.0f, 5, 0, 0, 1},
+        {"RF,RP=2,2", 131, 4, 8, 2, 2, 2.0f, 20000.0f, 5, 1, 0, 0},
+        {"RF,RP=4,4", 150, 4, 8, 4, 4, 2.0f, 20000.0f, 3, 1, 0, 0},
+        {"NW=4 RF,RP=6,4", 117, 4, 4, 6, 4, 3.0f, 20000.0f, 3, 1, 0, 0},
+        {"tiny grid 8", 8, 3, 8, 4, 2, 2.0f, 20000.0f, 1, 1, 0, 0},
+        {"grid 57 (two strips)", 57, 4, 8, 4, 2, 2.0f, 20000.0f, 2, 1, 0, 0},
+        {"many cylinders", 180, 3, 8, 4, 2, 2.0f, 20000.0f, 40, 1, 0, 0},
     };
     if (!quick) {
-        cases.push_back({"config-2 like 700, 3 steps", 700, 3, 8, 3, 2.0f, 20000.0f, 19, 1, 0, 0});
-        cases.push_back({"wide pml 4.0 at 300", 300, 5, 8, 3, 4.0f, 20000.0f, 8, 1, 0, 0});
+        cases.push_back({"config-2 like 700, 3 steps", 700, 3, 8, 4, 2, 2.0f, 20000.0f, 19, 1, 0, 0});
+        cases.push_back({"wide pml 4.0 at 300", 300, 5, 8, 4, 2, 4.0f, 20000.0f, 8, 1, 0, 0});
     }
     int fails = 0;
     for (const Case &c : cases) fails += run_case(c);

@@ -54,9 +54,10 @@ def test_linearity_in_source_amplitude_is_exact_for_powers_of_two(impl):
     s4, f4 = run(700, impl, 60, amp=4.0)
     # scaling by a power of two commutes with every fp32 rounding except in the subnormal range (the far tails of the
     # Gaussian): exact wherever the field is a normal number
-    big = np.abs(f1) > 1e-30
+    # (subnormal INTERMEDIATES -- dt*k products of tiny values -- also feed cells that are themselves tiny but normal)
+    big = np.abs(f1) > 1e-15
     assert big.sum() > 100000 and np.array_equal(f4[big], (f1 * f32(4.0))[big])
-    assert np.abs(f4 - f1 * f32(4.0)).max() < 1e-30
+    assert np.abs(f4 - f1 * f32(4.0)).max() < 1e-25
     assert np.allclose(s4, s1 * 16.0, rtol=1e-6)
 
 

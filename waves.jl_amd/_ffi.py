@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libwaves_amd.so")
+LIB_PATH = os.environ.get("WAVES_AMD_LIB") or os.path.join(CSRC, "libwaves_amd.so")  # override: A/B builds
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "include", "waves_amd.h"))
 
 WV_OK, WV_ERR_INVALID, WV_ERR_HIP, WV_ERR_NO_DEVICE, WV_ERR_NOMEM, WV_ERR_STATE = range(6)

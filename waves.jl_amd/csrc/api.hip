@@ -51,6 +51,10 @@ struct wv_ctx {
     size_t traj_cap = 0;
     float *d_small = nullptr;  // gaussian parameters
     size_t small_cap = 0;
+    float *d_elast = nullptr;  // per-block energy partials of the state the last integrate ended on
+    size_t elast_cap = 0;
+    int elast_generation = -1;
+    bool elast_valid = false;  // ... still describing the current state (so row 1 of a step == last row of the previous)
 
     FusedPlan *fused = nullptr;
 
@@ -203,7 +207,8 @@ int wv_destroy(wv_ctx *c)
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     float *bufs[] = {c->d_x, c->d_y, c->d_sx, c->d_sy, c->d_frames, c->d_scratch[0], c->d_scratch[1], c->d_yA, c->d_yB,
-                     c->d_acc, c->d_G, c->d_plane[0], c->d_plane[1], c->d_epart, c->d_signal, c->d_traj, c->d_small};
+                     c->d_acc, c->d_G, c->d_plane[0], c->d_plane[1], c->d_epart, c->d_signal, c->d_traj, c->d_small,
+                     c->d_elast};
     for (float *b : bufs)
         if (b) (void)hipFree(b);
     if (c->d_cyl) (void)hipFree(c->d_cyl);
@@ -347,6 +352,7 @@ int wv_set_frames(wv_ctx *c, const float *wave)
     HIPCHK(c, hipMemcpyAsync(c->d_frames, wave, 3 * c->N * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     fused_state_changed(c->fused);
+    c->elast_valid = false;
     return WV_OK;
 }
 
@@ -367,6 +373,7 @@ int wv_set_state(wv_ctx *c, const float *u)
     HIPCHK(c, hipMemcpyAsync(frame(c, 2), u, c->N * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     fused_state_changed(c->fused);
+    c->elast_valid = false;
     return WV_OK;
 }
 
@@ -386,6 +393,7 @@ int wv_reset(wv_ctx *c)
     HIPCHK(c, hipMemsetAsync(c->d_frames, 0, 3 * c->N * sizeof(float), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     fused_state_zeroed(c->fused);
+    c->elast_valid = false;
     return WV_OK;
 }
 
@@ -562,10 +570,19 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     if (M > 0)
         HIPCHK(c, hipMemcpyAsync(c->d_cyl, c->h_cyl.data(), c->h_cyl.size() * sizeof(Cyl), hipMemcpyHostToDevice, c->stream));
 
+    if (impl == WV_IMPL_FUSED) {
+        rc = fused_prepare(c->fused, c->d_frames, c->d_scratch[0], c->d_scratch[1], capture != 0, c->d_cyl,
+                           M > 0 ? c->h_cyl.data() : nullptr, M, 3 * nsteps, c->stream);
+        if (rc) return fail(c, rc == 2 ? WV_ERR_INVALID : WV_ERR_HIP, "fused_prepare failed");
+        if (fused_generation(c->fused) != c->elast_generation) c->elast_valid = false;
+        c->elast_generation = fused_generation(c->fused);
+    }
     const int nblocks = impl == WV_IMPL_STAGED ? staged_energy_blocks(c->grid) : fused_energy_blocks(c->fused);
-    const int init_blocks = nblocks;  // the initial state's partials use the same row width
     if (want_signal) {
         rc = ensure(c, &c->d_epart, &c->epart_cap, (size_t)(nsteps + 1) * nblocks * 3);
+        if (rc) return rc;
+        if ((size_t)nblocks * 3 > c->elast_cap) c->elast_valid = false;
+        rc = ensure(c, &c->d_elast, &c->elast_cap, (size_t)nblocks * 3);
         if (rc) return rc;
         rc = ensure(c, &c->d_signal, &c->signal_cap, (size_t)(nsteps + 1) * 3);
         if (rc) return rc;
@@ -581,11 +598,6 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
             c->kev.push_back(ev);
         }
     }
-    if (impl == WV_IMPL_FUSED) {
-        rc = fused_prepare(c->fused, c->d_frames, c->d_scratch[0], c->d_scratch[1], capture != 0, c->d_cyl,
-                           M > 0 ? c->h_cyl.data() : nullptr, M, 3 * nsteps, c->stream);
-        if (rc) return fail(c, WV_ERR_HIP, "fused_prepare failed");
-    }
 
     hipStream_t st = c->stream;
     HIPCHK(c, hipEventRecord(c->ev0, st));
@@ -595,8 +607,12 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
 
     float *cur = frame(c, 2);
     if (want_signal) {
-        if (init_blocks > 0) HIPCHK(c, hipMemsetAsync(c->d_epart, 0, (size_t)nblocks * 3 * sizeof(float), st));
-        launch_energy_partial(c->grid, cur, c->d_epart, nblocks, st);
+        // energies of the initial state: the very partial sums the previous call ended on when the state is unchanged
+        // (the reference sums the same array in both places, src/env.jl:105-111), else a fresh reduction
+        if (c->elast_valid)
+            HIPCHK(c, hipMemcpyAsync(c->d_epart, c->d_elast, (size_t)nblocks * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        else
+            launch_energy_partial(c->grid, cur, c->d_epart, nblocks, st);
     }
     if (want_fields) launch_copy_planes(cur, c->P, tt, ti_, st);
     if (capture && nsteps == 2 * WV_FRAMESKIP)
@@ -656,7 +672,12 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
         cur = out;
     }
     HIPCHK(c, hipGetLastError());
-    if (want_signal) launch_energy_final(c->d_epart, nsteps + 1, nblocks, c->dOmega, c->d_signal, st);
+    if (want_signal) {
+        launch_energy_final(c->d_epart, nsteps + 1, nblocks, c->dOmega, c->d_signal, st);
+        HIPCHK(c, hipMemcpyAsync(c->d_elast, c->d_epart + (size_t)nsteps * nblocks * 3, (size_t)nblocks * 3 * sizeof(float),
+                                 hipMemcpyDeviceToDevice, st));
+    }
+    c->elast_valid = want_signal != 0;
     HIPCHK(c, hipEventRecord(c->ev1, st));
     HIPCHK(c, hipGetLastError());
 
@@ -685,6 +706,7 @@ int wv_integrate_end(wv_ctx *c, float *signal, float *u_tot, float *u_inc)
         HIPCHK(c, hipMemcpyAsync(u_inc, c->d_traj + (size_t)(n + 1) * c->P, (size_t)(n + 1) * c->P * sizeof(float),
                                  hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+    if (c->timing.impl == WV_IMPL_FUSED) fused_dump_stamps(c->fused, st);
     float ms = 0.0f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->timing.total_ms = ms;
@@ -745,6 +767,8 @@ int wv_device_frames(wv_ctx *c, void **dptr, size_t *bytes)
     if (!dptr) return fail(c, WV_ERR_INVALID, "wv_device_frames: NULL");
     *dptr = c->d_frames;
     if (bytes) *bytes = 3 * c->N * sizeof(float);
+    fused_state_changed(c->fused);  // the caller may write through the pointer
+    c->elast_valid = false;
     return WV_OK;
 }
 

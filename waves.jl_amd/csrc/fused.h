@@ -26,7 +26,11 @@ void fused_set_pml(FusedPlan *p, const float *sx_host, const float *sy_host);
 // The caller replaced the state: the "auxiliary fields are zero outside the PML" fast-path precondition is unknown.
 void fused_state_changed(FusedPlan *p);
 void fused_state_zeroed(FusedPlan *p);
+// number of tiles == rows of the energy-partial array; valid after fused_prepare (the decomposition depends on whether
+// the 6-field fast path applies).  fused_generation changes whenever the decomposition does.
 int fused_energy_blocks(FusedPlan *p);
+int fused_generation(const FusedPlan *p);
+void fused_dump_stamps(FusedPlan *p, hipStream_t s);  // diagnostic, no-op unless WAVES_AMD_STAMPS is set
 // Called once per wv_integrate before the first step: d_table = device cylinder table (rows x M), h_table its host copy.
 // frames = env.wave (3 states, the last one is the initial condition), scratch0/1 the two ping-pong states.
 int fused_prepare(FusedPlan *p, float *frames, float *scratch0, float *scratch1, bool capture, const Cyl *d_table,

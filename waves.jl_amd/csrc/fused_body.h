@@ -62,14 +62,19 @@ struct FusedParams {
     float *epart;     // [ntiles][3] or nullptr
     float *traj_tot;  // optional copies of the new U_tot / U_inc planes
     float *traj_inc;
+    unsigned long long *stamps;  // diagnostic: [ntiles][16] shader-clock stamps per phase, or nullptr (normal runs)
 };
 
-template <int RY>
+// LDS image of one tile: three (RY + 2) x FT_LX arrays of (total, incident) pairs carved out of one raw buffer (the
+// kernel instantiates variants with different RY over the same allocation).
 struct FusedLds {
-    F2 W[(RY + 2) * FT_LX];
-    F2 Vx[(RY + 2) * FT_LX];
-    F2 Vy[(RY + 2) * FT_LX];
+    F2 *W, *Vx, *Vy;
 };
+constexpr int lds_elems(int RY) { return 3 * (RY + 2) * FT_LX; }
+WV_HD FusedLds lds_view(F2 *raw, int RY)
+{
+    return FusedLds{raw, raw + (RY + 2) * FT_LX, raw + 2 * (RY + 2) * FT_LX};
+}
 
 WV_HD int lds_at(int lx, int ly) { return (ly + 1) * FT_LX + (lx + 1); }
 
@@ -146,7 +151,7 @@ WV_HD void fused_load(const FusedParams &p, const TileDesc &t, int tid, FusedReg
 
 // ---- phase "publish": the stage input's stencil fields -> LDS ------------------------------------------------
 template <bool PML, bool EDGE, int NW, int RPT, int S>
-WV_HD void fused_publish(const FusedParams &p, const TileDesc &t, int tid, FusedLds<NW * RPT> &lds,
+WV_HD void fused_publish(const FusedParams &p, const TileDesc &t, int tid, const FusedLds &lds,
                          const FusedRegs<PML, RPT> &r)
 {
     const int lane = tid & 63, w = tid >> 6;
@@ -192,7 +197,7 @@ WV_HD F2 edge_deriv(const Ops &o, const F2 *v, int i, int st, int g, int n)
 
 // ---- phase "compute": k_S from the LDS image, then the RK update of the registers ----------------------------
 template <bool PML, bool EDGE, int NW, int RPT, int S>
-WV_HD void fused_compute(const FusedParams &p, const TileDesc &t, int tid, const FusedLds<NW * RPT> &lds,
+WV_HD void fused_compute(const FusedParams &p, const TileDesc &t, int tid, const FusedLds &lds,
                          FusedRegs<PML, RPT> &r)
 {
     constexpr int NS = FusedRegs<PML, RPT>::NS;

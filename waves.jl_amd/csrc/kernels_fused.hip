@@ -5,6 +5,7 @@
 // Roofline: HBM-bound by contract (104 algorithmic bytes per cell-update).  Per launch the kernel reads the
 // 12-field state once plus a 4-cell halo ring per tile (x 64/56 in x, x RY/(RY-8) in y) and writes it once; the wave
 // speed is evaluated from <= a handful of culled cylinders per tile in registers, so no c-field is ever materialised.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <vector>
@@ -17,37 +18,59 @@ namespace wv {
 namespace {
 
 template <bool PML, bool EDGE, int NW, int RPT>
-__device__ __forceinline__ void run_tile(const FusedParams &p, const TileDesc &t, FusedLds<NW * RPT> &lds, float e[3])
+__device__ __forceinline__ void run_tile(const FusedParams &p, const TileDesc &t, F2 *raw, float e[3])
 {
     const int tid = threadIdx.x;
+    const FusedLds lds = lds_view(raw, NW * RPT);
     FusedRegs<PML, RPT> r;
+    // diagnostic stamps (p.stamps == nullptr in every normal run: one block-uniform branch per phase)
+    unsigned long long *st = p.stamps ? p.stamps + (size_t)t.slot * 16 : nullptr;
+#define WV_STAMP(k)                                                     \
+    if (st && tid == 0) {                                               \
+        __builtin_amdgcn_s_waitcnt(0);                                  \
+        st[k] = __builtin_amdgcn_s_memtime();                           \
+    }
+    WV_STAMP(0)
     fused_load<PML, EDGE, NW, RPT>(p, t, tid, r);
 #define WV_STAGE(S)                                          \
     fused_publish<PML, EDGE, NW, RPT, S>(p, t, tid, lds, r); \
     __syncthreads();                                         \
+    WV_STAMP(2 * S - 1)                                      \
     fused_compute<PML, EDGE, NW, RPT, S>(p, t, tid, lds, r); \
-    if (S < 4) __syncthreads();
+    if (S < 4) __syncthreads();                              \
+    WV_STAMP(2 * S)
     WV_STAGE(1)
     WV_STAGE(2)
     WV_STAGE(3)
     WV_STAGE(4)
 #undef WV_STAGE
     fused_store<PML, EDGE, NW, RPT>(p, t, tid, r, e);
+    WV_STAMP(9)
+    if (st && tid == 0) {
+        st[10] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID, all 32 bits
+        st[11] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+        st[12] = __builtin_amdgcn_s_memrealtime();
+        st[13] = (unsigned long long)t.variant;
+    }
+#undef WV_STAMP
 }
 
-template <int NW, int RPT>
+// RF / RP: rows per thread of the 6-field FAST tiles / of the 12-field MID and GEN tiles (a FAST thread carries half
+// the state per cell, so it can own twice the cells at the same register budget).
+template <int NW, int RF, int RP>
 __global__ __launch_bounds__(NW * 64) void k_step_fused(FusedParams p)
 {
-    __shared__ FusedLds<NW * RPT> lds;
+    constexpr int RYMAX = NW * (RF > RP ? RF : RP);
+    __shared__ F2 raw[lds_elems(RYMAX)];
     __shared__ float red[3][NW];
     const TileDesc t = p.tiles[blockIdx.x];
     float e[3];
     if (t.variant == VAR_FAST)
-        run_tile<false, false, NW, RPT>(p, t, lds, e);
+        run_tile<false, false, NW, RF>(p, t, raw, e);
     else if (t.variant == VAR_MID)
-        run_tile<true, false, NW, RPT>(p, t, lds, e);
+        run_tile<true, false, NW, RP>(p, t, raw, e);
     else
-        run_tile<true, true, NW, RPT>(p, t, lds, e);
+        run_tile<true, true, NW, RP>(p, t, raw, e);
     if (p.epart) {  // block-uniform
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -98,10 +121,12 @@ __global__ __launch_bounds__(256) void k_aux_clean(float *__restrict__ state, in
 
 struct FusedPlan {
     Grid g{};
-    int NW = 8, RPT = 3;
+    int NW = 8, RF = 4, RP = 2;   // rows per thread: FAST tiles / MID+GEN tiles
+    bool xcd_aware = true;
     std::vector<float> x, y, sx, sy;
     HostPlan hp;
     bool tiles_valid = false;
+    int generation = 0;           // bumped whenever the tile decomposition changes
     bool tiles_aux_zero = false;  // the aux_zero value the current tile classification was built with
     int aux_state = 1;            // initial condition: 1 zero outside the PML, 0 not, -1 unknown
     bool scratch_clean = true;    // the two scratch states have zero auxiliary planes outside the PML
@@ -114,6 +139,9 @@ struct FusedPlan {
     int *d_flag = nullptr;
     const Cyl *d_table = nullptr;
     int M = 0;
+    unsigned long long *d_stamps = nullptr;  // diagnostic (WAVES_AMD_STAMPS=<file>)
+    size_t stamps_cap = 0;
+    const char *stamps_path = nullptr;
 };
 
 FusedPlan *fused_create(const Grid &g, const float *x, const float *y, const float *sx, const float *sy)
@@ -125,10 +153,15 @@ FusedPlan *fused_create(const Grid &g, const float *x, const float *y, const flo
     p->y.assign(y, y + g.ny);
     p->sx.assign(sx, sx + g.nx);
     p->sy.assign(sy, sy + g.ny);
-    if (const char *e = getenv("WAVES_AMD_FUSED_RPT")) {
-        const int v = atoi(e);
-        if (v == 2 || v == 3 || v == 4) p->RPT = v;
+    if (const char *e = getenv("WAVES_AMD_FUSED_TILES")) {  // tuning knob: "RF,RP" in {4,2 | 3,2 | 3,3 | 2,2}
+        int a = 0, b = 0;
+        if (sscanf(e, "%d,%d", &a, &b) == 2 && ((a == 4 && b == 2) || (a == 3 && b == 2) || (a == 3 && b == 3) || (a == 2 && b == 2))) {
+            p->RF = a;
+            p->RP = b;
+        }
     }
+    if (const char *e = getenv("WAVES_AMD_FUSED_XCD")) p->xcd_aware = atoi(e) != 0;
+    p->stamps_path = getenv("WAVES_AMD_STAMPS");
     if (hipMalloc((void **)&p->d_flag, sizeof(int)) != hipSuccess) {
         delete p;
         return nullptr;
@@ -142,6 +175,7 @@ void fused_destroy(FusedPlan *p)
     if (p->d_tiles) (void)hipFree(p->d_tiles);
     if (p->d_idx) (void)hipFree(p->d_idx);
     if (p->d_flag) (void)hipFree(p->d_flag);
+    if (p->d_stamps) (void)hipFree(p->d_stamps);
     delete p;
 }
 
@@ -170,11 +204,12 @@ void fused_state_zeroed(FusedPlan *p)
 static bool ensure_tiles(FusedPlan *p, bool aux_zero)
 {
     if (p->tiles_valid && p->tiles_aux_zero == aux_zero) return true;
-    if (!plan_build_tiles(p->hp, p->g.nx, p->g.ny, p->NW * p->RPT, p->x.data(), p->y.data(), p->sx.data(),
-                          p->sy.data(), aux_zero))
+    if (!plan_build_tiles(p->hp, p->g.nx, p->g.ny, p->NW * p->RF, p->NW * p->RP, p->x.data(), p->y.data(),
+                          p->sx.data(), p->sy.data(), aux_zero, p->xcd_aware))
         return false;
     p->tiles_valid = true;
     p->tiles_aux_zero = aux_zero;
+    p->generation++;
     return true;
 }
 
@@ -273,12 +308,46 @@ void fused_launch(FusedPlan *pl, const FusedStep &st, hipStream_t s)
     p.epart = st.epart;
     p.traj_tot = st.traj_tot;
     p.traj_inc = st.traj_inc;
-    const dim3 grid((unsigned)pl->hp.tiles.size());
-    switch (pl->RPT) {
-        case 2: hipLaunchKernelGGL((k_step_fused<8, 2>), grid, dim3(512), 0, s, p); break;
-        case 4: hipLaunchKernelGGL((k_step_fused<8, 4>), grid, dim3(512), 0, s, p); break;
-        default: hipLaunchKernelGGL((k_step_fused<8, 3>), grid, dim3(512), 0, s, p); break;
+    p.stamps = nullptr;
+    if (pl->stamps_path) {
+        const size_t need = pl->hp.tiles.size() * 16;
+        if (need > pl->stamps_cap) {
+            if (pl->d_stamps) (void)hipFree(pl->d_stamps);
+            pl->d_stamps = nullptr;
+            if (hipMalloc((void **)&pl->d_stamps, need * sizeof(unsigned long long)) == hipSuccess) pl->stamps_cap = need;
+        }
+        p.stamps = pl->d_stamps;
     }
+    const dim3 grid((unsigned)pl->hp.tiles.size());
+    const int key = pl->RF * 10 + pl->RP;
+    switch (key) {
+        case 32: hipLaunchKernelGGL((k_step_fused<8, 3, 2>), grid, dim3(512), 0, s, p); break;
+        case 33: hipLaunchKernelGGL((k_step_fused<8, 3, 3>), grid, dim3(512), 0, s, p); break;
+        case 22: hipLaunchKernelGGL((k_step_fused<8, 2, 2>), grid, dim3(512), 0, s, p); break;
+        default: hipLaunchKernelGGL((k_step_fused<8, 4, 2>), grid, dim3(512), 0, s, p); break;
+    }
+}
+
+int fused_generation(const FusedPlan *p) { return p->generation; }
+
+// diagnostic: write the phase stamps of the LAST launched step, with the tile list, to WAVES_AMD_STAMPS (text)
+void fused_dump_stamps(FusedPlan *p, hipStream_t s)
+{
+    if (!p->stamps_path || !p->d_stamps) return;
+    const size_t nt = p->hp.tiles.size();
+    std::vector<unsigned long long> h(nt * 16);
+    if (hipStreamSynchronize(s) != hipSuccess) return;
+    if (hipMemcpy(h.data(), p->d_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return;
+    FILE *f = fopen(p->stamps_path, "w");
+    if (!f) return;
+    fprintf(f, "# pos slot x0 y0 ox oy variant cyl | t0..t9 xcc hwid realtime variant\n");
+    for (size_t i = 0; i < nt; ++i) {
+        const TileDesc &t = p->hp.tiles[i];
+        fprintf(f, "%zu %d %d %d %d %d %d %d |", i, t.slot, t.x0, t.y0, t.ox, t.oy, t.variant, t.cyl_count);
+        for (int k = 0; k < 14; ++k) fprintf(f, " %llu", h[(size_t)t.slot * 16 + k]);
+        fprintf(f, "\n");
+    }
+    fclose(f);
 }
 
 void fused_variant_counts(const FusedPlan *p, int out[3])

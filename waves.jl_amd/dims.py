@@ -10,21 +10,28 @@ f32 = np.float32
 
 def _range_f32(start, stop, n: int) -> np.ndarray:
     """`collect(range(start::Float32, stop::Float32, n))`: Julia evaluates Float32 ranges in twice precision, i.e.
-    each element is the exact affine interpolant of the two Float32 endpoints rounded once to Float32."""
-    a, b = Fraction(float(f32(start))), Fraction(float(f32(stop)))
-    out = np.empty(n, dtype=np.float32)
+    each element is the exact affine interpolant of the two Float32 endpoints rounded once to Float32.  Evaluated in
+    float64 (vectorised); the rare elements that land within 1e-9 ulp of a Float32 rounding boundary are redone in exact
+    rational arithmetic so the single rounding is honoured."""
+    a64, b64 = float(f32(start)), float(f32(stop))
     if n == 1:
-        out[0] = f32(start)
-        return out
-    for i in range(n):
-        q = a + (b - a) * Fraction(i, n - 1)
-        s = f32(float(q))
-        best, bd = s, abs(Fraction(float(s)) - q)
-        for cand in (np.nextafter(s, f32(-np.inf)), np.nextafter(s, f32(np.inf))):
-            d = abs(Fraction(float(cand)) - q)
-            if d < bd:
-                best, bd = cand, d
-        out[i] = best
+        return np.array([f32(start)], dtype=np.float32)
+    i = np.arange(n, dtype=np.float64)
+    x = a64 + (b64 - a64) * i / (n - 1)
+    out = x.astype(np.float32)
+    # distance of the float64 value to the midpoint between the two neighbouring float32 values
+    other = np.where(out.astype(np.float64) > x, np.nextafter(out, np.float32(-np.inf)), np.nextafter(out, np.float32(np.inf)))
+    mid = 0.5 * (out.astype(np.float64) + other.astype(np.float64))
+    ulp = np.abs(out.astype(np.float64) - other.astype(np.float64))
+    risky = np.abs(x - mid) <= 1e-9 * ulp
+    risky[0] = risky[-1] = False
+    out[0], out[-1] = f32(start), f32(stop)
+    if risky.any():
+        a, b = Fraction(a64), Fraction(b64)
+        for k in np.nonzero(risky)[0]:
+            q = a + (b - a) * Fraction(int(k), n - 1)
+            cands = [out[k], np.nextafter(out[k], f32(-np.inf)), np.nextafter(out[k], f32(np.inf))]
+            out[k] = min(cands, key=lambda c: abs(Fraction(float(c)) - q))
     return out
 
 
