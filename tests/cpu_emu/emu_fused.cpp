@@ -27,33 +27,37 @@ using namespace wv;
 
 static F2 g_lds_raw[lds_elems(8 * 6)];  // deliberately NOT cleared between tiles: stale contents must never matter
 
-template <bool PML, bool EDGE, int NW, int RPT>
+template <int AUX, int NW, int RPT, int RYMAX>
 static void run_tile(const FusedParams &p, const TileDesc &t, double esum[3])
 {
     constexpr int NT = NW * 64;
-    const FusedLds lds = lds_view(g_lds_raw, NW * RPT);
-    std::vector<FusedRegs<PML, RPT>> regs(NT);
-    for (int tid = 0; tid < NT; ++tid) fused_load<PML, EDGE, NW, RPT>(p, t, tid, regs[tid]);
-#define STAGE(S)                                                                                            \
-    for (int tid = 0; tid < NT; ++tid) fused_publish<PML, EDGE, NW, RPT, S>(p, t, tid, lds, regs[tid]);     \
-    for (int tid = 0; tid < NT; ++tid) fused_compute<PML, EDGE, NW, RPT, S>(p, t, tid, lds, regs[tid]);
+    const FusedLds lds = lds_view(g_lds_raw, NW * RPT, RYMAX);
+    std::vector<FusedRegs<AUX, RPT>> regs(NT);
+    for (int tid = 0; tid < NT; ++tid) fused_load<AUX, NW, RPT>(p, t, tid, lds, regs[tid]);
+#define STAGE(S)                                                                                   \
+    for (int tid = 0; tid < NT; ++tid) fused_publish<AUX, NW, RPT, S>(p, t, tid, lds, regs[tid]);  \
+    for (int tid = 0; tid < NT; ++tid) fused_compute<AUX, NW, RPT, S>(p, t, tid, lds, regs[tid]);
     STAGE(1) STAGE(2) STAGE(3) STAGE(4)
 #undef STAGE
     for (int tid = 0; tid < NT; ++tid) {
         float e[3];
-        fused_store<PML, EDGE, NW, RPT>(p, t, tid, regs[tid], e);
+        fused_store<AUX, NW, RPT>(p, t, tid, regs[tid], e);
         for (int c = 0; c < 3; ++c) esum[c] += (double)e[c];
     }
 }
 
-template <int NW, int RF, int RP>
+template <int NW, int RF, int RB, int RP>
 static void run_step(const FusedParams &p, const HostPlan &pl, double esum[3])
 {
+    constexpr int RMAX = RF > RB ? (RF > RP ? RF : RP) : (RB > RP ? RB : RP);
+    constexpr int RYMAX = NW * RMAX;
+    static_assert(RYMAX <= 48, "g_lds_raw too small");
     for (const TileDesc &t : pl.tiles) {
-        switch (t.variant) {
-            case VAR_FAST: run_tile<false, false, NW, RF>(p, t, esum); break;
-            case VAR_MID: run_tile<true, false, NW, RP>(p, t, esum); break;
-            default: run_tile<true, true, NW, RP>(p, t, esum); break;
+        switch (t.aux) {
+            case AUX_NONE: run_tile<AUX_NONE, NW, RF, RYMAX>(p, t, esum); break;
+            case AUX_PX: run_tile<AUX_PX, NW, RB, RYMAX>(p, t, esum); break;
+            case AUX_PY: run_tile<AUX_PY, NW, RB, RYMAX>(p, t, esum); break;
+            default: run_tile<AUX_ALL, NW, RP, RYMAX>(p, t, esum); break;
         }
     }
 }
@@ -71,11 +75,13 @@ struct Case {
     const char *name;
     int n;
     int nsteps;
-    int NW, RF, RP;  // waves per block; rows per thread of FAST / MID+GEN tiles
+    int NW, RF, RB, RP;  // waves per block; rows per thread of AUX_NONE / AUX_PX+PY / AUX_ALL tiles
     float pml_width, pml_scale;
     int M;           // cylinders
     int source;      // 0/1
-    int aux;         // 1: random non-zero auxiliary fields everywhere (forces MID tiles); 0: aux zero -> FAST tiles
+    int aux;         // 1: random non-zero auxiliary fields everywhere (forces AUX_ALL tiles); 0: only where they may be
+                     // non-zero (Psi_x where sigma_x != 0, ...) -> reduced field sets
+    int src_mode = 1;  // 1: per-tile source flags computed; 0: src_flags = nullptr (assume non-zero everywhere)
     int force_all;   // 1: natural launch order instead of the XCD-aware one
 };
 
@@ -95,9 +101,10 @@ static int run_case(const Case &cs)
         for (size_t q = 0; q < P; ++q) {
             const int i = (int)(q % n), j = (int)(q / n);
             float v = (float)(0.1 * (urand() - 0.5));
-            if (is_aux) {
-                const bool in_pml = sx[i] != 0.0f || sx[j] != 0.0f;
-                if (!cs.aux && !in_pml) v = 0.0f;
+            if (is_aux && !cs.aux) {
+                const int k = f % 6;  // 3: Psi_x, 4: Psi_y, 5: Omega
+                const bool zx = sx[i] == 0.0f, zy = sx[j] == 0.0f;
+                if ((k == 3 && zx) || (k == 4 && zy) || (k == 5 && (zx || zy))) v = 0.0f;
             }
             u0[(size_t)f * P + q] = v;
         }
@@ -106,7 +113,7 @@ static int run_case(const Case &cs)
     if (cs.source)
         for (size_t q = 0; q < P; ++q) {
             const float xx = x[q % n] - 1.0f, yy = x[q / n] + 0.5f;
-            G[q] = (float)exp(-(xx * xx + yy * yy) / 2.0);
+            G[q] = (float)exp(-(xx * xx + yy * yy) / 0.18);  // underflows to exactly 0 ~4.4 units away, like the env's source
         }
     const int M = cs.M;
     std::vector<float> d0(4 * (size_t)(M ? M : 1)), d1(4 * (size_t)(M ? M : 1));
@@ -150,14 +157,20 @@ static int run_case(const Case &cs)
         }
     }
     HostPlan pl;
-    if (!plan_build_tiles(pl, n, n, cs.NW * cs.RF, cs.NW * cs.RP, x.data(), x.data(), sx.data(), sx.data(), cs.aux == 0,
-                          cs.force_all == 0)) {
+    if (!plan_build_tiles(pl, n, n, cs.NW * cs.RF, cs.NW * cs.RB, cs.NW * cs.RP, x.data(), x.data(), sx.data(), sx.data(),
+                          cs.aux == 0, cs.force_all == 0)) {
         printf("%-28s plan_build_tiles failed\n", cs.name);
         return 1;
     }
     std::vector<int> idx;
     plan_build_cyl(pl, x.data(), x.data(), table.data(), M, 3 * nsteps, idx);
 
+    // per-tile source flags exactly as k_src_flags computes them
+    std::vector<unsigned char> flags(pl.tiles.size(), 0);
+    for (const TileDesc &t : pl.tiles)
+        for (int gy = t.y0 - FT_H; gy < t.y0 + t.oy + FT_H; ++gy)
+            for (int gx = t.x0 - FT_H; gx < t.x0 + t.ox + FT_H; ++gx)
+                if (gx >= 0 && gx < n && gy >= 0 && gy < n && G[(size_t)gy * n + gx] != 0.0f) flags[t.slot] = 1;
     std::vector<float> bufA = u0, bufB(N, 0.0f);
     if (cs.aux) {  // a dirty output buffer must not matter when no FAST tile exists
         for (size_t q = 0; q < N; ++q) bufB[q] = 123.0f;
@@ -166,26 +179,28 @@ static int run_case(const Case &cs)
     double emax = 0.0;
     for (int s = 0; s < nsteps; ++s) {
         FusedParams p{};
-        p.nx = n; p.ny = n; p.P = P;
+        p.nx = n; p.ny = n; p.P = (unsigned)P;
         const float delta = (x[n - 1] - x[0]) / (float)(n - 1), two_d = 2.0f * delta;
         p.ops = Ops{-1.0f / two_d, 1.0f / two_d, -3.0f / two_d, 4.0f / two_d, -1.0f / two_d, 1.0f / two_d, -4.0f / two_d, 3.0f / two_d};
         p.x = x.data(); p.y = x.data(); p.sx = sx.data(); p.sy = sx.data();
         p.c0 = c0; p.c0sq = c0 * c0;
         p.u = cur; p.out = nxt; p.G = cs.source ? G.data() : nullptr;
+        p.src_flags = (cs.source && cs.src_mode) ? flags.data() : nullptr;
         p.sfac[0] = sfac[3 * s]; p.sfac[1] = sfac[3 * s + 1]; p.sfac[2] = sfac[3 * s + 2];
         p.cyl = table.data() + (size_t)(3 * s) * M; p.M = M;
         p.dt = dt; p.hdt = hdt;
         p.tiles = pl.tiles.data(); p.cyl_idx = idx.data();
-        p.epart = nullptr; p.traj_tot = nullptr; p.traj_inc = nullptr;
+        p.epart = nullptr; p.traj_tot = nullptr; p.traj_inc = nullptr; p.stamps = nullptr;
         double es[3] = {0, 0, 0};
-        const int key = cs.NW * 100 + cs.RF * 10 + cs.RP;
-        if (key == 842) run_step<8, 4, 2>(p, pl, es);
-        else if (key == 832) run_step<8, 3, 2>(p, pl, es);
-        else if (key == 833) run_step<8, 3, 3>(p, pl, es);
-        else if (key == 822) run_step<8, 2, 2>(p, pl, es);
-        else if (key == 844) run_step<8, 4, 4>(p, pl, es);
-        else if (key == 464) run_step<4, 6, 4>(p, pl, es);
-        else { printf("unsupported NW/RF/RP\n"); return 1; }
+        const int key = cs.NW * 1000 + cs.RF * 100 + cs.RB * 10 + cs.RP;
+        if (key == 8432) run_step<8, 4, 3, 2>(p, pl, es);
+        else if (key == 8332) run_step<8, 3, 3, 2>(p, pl, es);
+        else if (key == 8322) run_step<8, 3, 2, 2>(p, pl, es);
+        else if (key == 8222) run_step<8, 2, 2, 2>(p, pl, es);
+        else if (key == 8333) run_step<8, 3, 3, 3>(p, pl, es);
+        else if (key == 8422) run_step<8, 4, 2, 2>(p, pl, es);
+        else if (key == 4644) run_step<4, 6, 4, 4>(p, pl, es);
+        else { printf("unsupported NW/RF/RB/RP\n"); return 1; }
         for (int c = 0; c < 3; ++c) {
             const double r = eref[3 * (size_t)(s + 1) + c];
             const double rel = fabs(es[c] - r) / (fabs(eref[3 * (size_t)(s + 1)]) + 1e-300);
@@ -202,8 +217,10 @@ static int run_case(const Case &cs)
         }
     double umax = 0;
     for (size_t q = 0; q < P; ++q) umax = fmax(umax, fabs(ref[q]));
-    printf("%-28s n=%4d steps=%3d NW,RF,RP=%d,%d,%d tiles FAST/MID/GEN=%d/%d/%d  culled-list=%zu  max|U|=%.3g  energy rel=%.1e  %s",
-           cs.name, n, nsteps, cs.NW, cs.RF, cs.RP, pl.count[0], pl.count[1], pl.count[2], idx.size(), umax, emax,
+    int nedge = 0;
+    for (const TileDesc &t : pl.tiles) nedge += t.edge ? 1 : 0;
+    printf("%-28s n=%4d steps=%3d NW,RF,RB,RP=%d,%d,%d,%d tiles NONE/PX/PY/ALL=%d/%d/%d/%d edge=%d  culled-list=%zu  max|U|=%.3g  energy rel=%.1e  %s",
+           cs.name, n, nsteps, cs.NW, cs.RF, cs.RB, cs.RP, pl.count[0], pl.count[1], pl.count[2], pl.count[3], nedge, idx.size(), umax, emax,
            bad ? "MISMATCH" : "bit-exact\n");
     if (bad) {
         const size_t f = first / P, q = first % P;
@@ -216,22 +233,26 @@ int main(int argc, char **argv)
 {
     const bool quick = argc > 1 && !strcmp(argv[1], "quick");
     std::vector<Case> cases = {
-        {"default tiles, design+src", 160, 6, 8, 4, 2, 2.0f, 20000.0f, 6, 1, 0, 0},
-        {"all-mid (aux everywhere)", 96, 5, 8, 4, 2, 2.0f, 20000.0f, 4, 1, 1, 0},
-        {"aux everywhere, 260", 260, 3, 8, 4, 2, 2.0f, 20000.0f, 4, 1, 1, 0},
-        {"no pml (scale 0), no design", 130, 5, 8, 4, 2, 1.0f, 0.0f, 0, 1, 0, 0},
-        {"RF,RP=3,2", 231, 4, 8, 3, 2, 2.0f, 20000.0f, 5, 1, 0, 0},
-        {"RF,RP=3,3 natural order", 200, 4, 8, 3, 3, 2.0f, 20000.0f, 5, 0, 0, 1},
-        {"RF,RP=2,2", 131, 4, 8, 2, 2, 2.0f, 20000.0f, 5, 1, 0, 0},
-        {"RF,RP=4,4", 150, 4, 8, 4, 4, 2.0f, 20000.0f, 3, 1, 0, 0},
-        {"NW=4 RF,RP=6,4", 117, 4, 4, 6, 4, 3.0f, 20000.0f, 3, 1, 0, 0},
-        {"tiny grid 8", 8, 3, 8, 4, 2, 2.0f, 20000.0f, 1, 1, 0, 0},
-        {"grid 57 (two strips)", 57, 4, 8, 4, 2, 2.0f, 20000.0f, 2, 1, 0, 0},
-        {"many cylinders", 180, 3, 8, 4, 2, 2.0f, 20000.0f, 40, 1, 0, 0},
+        {"default tiles, design+src", 160, 6, 8, 4, 3, 2, 2.0f, 20000.0f, 6, 1, 0, 0},
+        {"aux everywhere (all AUX_ALL)", 96, 5, 8, 4, 3, 2, 2.0f, 20000.0f, 4, 1, 1, 0},
+        {"aux everywhere, 260", 260, 3, 8, 4, 3, 2, 2.0f, 20000.0f, 4, 1, 1, 0},
+        {"no pml (scale 0), no design", 130, 5, 8, 4, 3, 2, 1.0f, 0.0f, 0, 1, 0, 0},
+        {"no src flags", 231, 4, 8, 4, 3, 2, 2.0f, 20000.0f, 5, 1, 0, 0, 0},
+        {"RF,RB,RP=3,3,2", 231, 4, 8, 3, 3, 2, 2.0f, 20000.0f, 5, 1, 0, 0},
+        {"3,3,3 natural order", 200, 4, 8, 3, 3, 3, 2.0f, 20000.0f, 5, 0, 0, 1},
+        {"2,2,2", 131, 4, 8, 2, 2, 2, 2.0f, 20000.0f, 5, 1, 0, 0},
+        {"4,2,2", 150, 4, 8, 4, 2, 2, 2.0f, 20000.0f, 3, 1, 0, 0},
+        {"NW=4 6,4,4", 117, 4, 4, 6, 4, 4, 3.0f, 20000.0f, 3, 1, 0, 0},
+        {"tiny grid 8", 8, 3, 8, 4, 3, 2, 2.0f, 20000.0f, 1, 1, 0, 0},
+        {"tiny grid 9, no pml", 9, 3, 8, 4, 3, 2, 2.0f, 0.0f, 1, 1, 0, 0},
+        {"grid 57 (two strips)", 57, 4, 8, 4, 3, 2, 2.0f, 20000.0f, 2, 1, 0, 0},
+        {"many cylinders", 180, 3, 8, 4, 3, 2, 2.0f, 20000.0f, 40, 1, 0, 0},
     };
     if (!quick) {
-        cases.push_back({"config-2 like 700, 3 steps", 700, 3, 8, 4, 2, 2.0f, 20000.0f, 19, 1, 0, 0});
-        cases.push_back({"wide pml 4.0 at 300", 300, 5, 8, 4, 2, 4.0f, 20000.0f, 8, 1, 0, 0});
+        cases.push_back({"config-2 like 700, 3 steps", 700, 3, 8, 4, 3, 2, 2.0f, 20000.0f, 19, 1, 0, 0});
+        cases.push_back({"wide pml 4.0 at 300", 300, 5, 8, 4, 3, 2, 4.0f, 20000.0f, 8, 1, 0, 0});
+        cases.push_back({"thin pml 0.5 at 300", 300, 5, 8, 4, 3, 2, 0.5f, 20000.0f, 8, 1, 0, 0});
+        cases.push_back({"600 cylinders (global-list path)", 200, 3, 8, 4, 3, 2, 2.0f, 20000.0f, 600, 1, 0, 0});
     }
     int fails = 0;
     for (const Case &c : cases) fails += run_case(c);

@@ -51,6 +51,33 @@ __global__ void k(float *out, int iters, unsigned long long *cyc)
                 asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
                              : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pm), "v"(pc));
             }
+        } else if (MODE == 7) {  // v_mov_b32_dpp wave_shr:1
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                asm volatile("s_nop 1\n v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+                             "v_mov_b32_dpp %2, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+                             "v_mov_b32_dpp %4, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %6 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+                             "v_mov_b32_dpp %6, %7 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            }
+        } else if (MODE == 8) {  // v_sub_f32_dpp with a wave_shl:1 operand
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                asm volatile("s_nop 1\n v_sub_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf\n v_sub_f32_dpp %1, %2, %3 wave_shl:1 row_mask:0xf bank_mask:0xf\n"
+                             "v_sub_f32_dpp %2, %3, %4 wave_shl:1 row_mask:0xf bank_mask:0xf\n v_sub_f32_dpp %3, %4, %5 wave_shl:1 row_mask:0xf bank_mask:0xf\n"
+                             "v_sub_f32_dpp %4, %5, %6 wave_shl:1 row_mask:0xf bank_mask:0xf\n v_sub_f32_dpp %5, %6, %7 wave_shl:1 row_mask:0xf bank_mask:0xf\n"
+                             "v_sub_f32_dpp %6, %7, %0 wave_shl:1 row_mask:0xf bank_mask:0xf\n v_sub_f32_dpp %7, %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            }
+        } else if (MODE == 9) {  // ds_bpermute-free LDS comparison: ds_read_b64 + ds_write_b64 pairs are measured elsewhere
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                asm volatile("s_nop 1\n v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                             "v_mov_b32_dpp %2, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                             "v_mov_b32_dpp %4, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                             "v_mov_b32_dpp %6, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            }
         } else {  // v_mov_b32
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -91,7 +118,7 @@ int main()
 {
     float *d_out; unsigned long long *d_cyc;
     hipMalloc(&d_out, 256 * 1024 * sizeof(float)); hipMalloc(&d_cyc, 256 * sizeof(unsigned long long));
-    for (int threads : {256, 512, 1024}) {
+    for (int threads : {512, 1024}) {
         run<0>("v_mul_f32", threads, d_out, d_cyc);
         run<1>("v_add_f32", threads, d_out, d_cyc);
         run<4>("v_fma_f32", threads, d_out, d_cyc);
@@ -99,6 +126,9 @@ int main()
         run<3>("v_pk_add_f32", threads, d_out, d_cyc);
         run<5>("v_pk_fma_f32", threads, d_out, d_cyc);
         run<6>("v_mov_b32", threads, d_out, d_cyc);
+        run<7>("mov_dpp wave_shr", threads, d_out, d_cyc);
+        run<8>("sub_dpp wave_shl", threads, d_out, d_cyc);
+        run<9>("mov_dpp row_shr", threads, d_out, d_cyc);
     }
     return 0;
 }

@@ -231,6 +231,8 @@ int wv_create(const wv_config *cfg, const float *x, const float *y, wv_ctx **out
                     "wv_create: nx must equal ny (the reference uses the x gradient matrix and the transposed x PML "
                     "profile for y: src/dynamics.jl:146,161-162)");
     if (!(cfg->dt > 0.0f)) return fail(nullptr, WV_ERR_INVALID, "wv_create: dt must be > 0");
+    if ((size_t)cfg->nx * cfg->ny * kFields >= ((size_t)1 << 31))
+        return fail(nullptr, WV_ERR_INVALID, "wv_create: 12*nx*ny must be < 2^31 (32-bit element offsets in the kernels)");
     if (cfg->impl < WV_IMPL_AUTO || cfg->impl > WV_IMPL_FUSED) return fail(nullptr, WV_ERR_INVALID, "wv_create: bad impl");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -409,6 +411,7 @@ int wv_set_source_shape(wv_ctx *c, const float *shape, float freq)
         HIPCHK(c, hipMemsetAsync(c->d_G, 0, c->P * sizeof(float), c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    fused_source_changed(c->fused);
     return WV_OK;
 }
 
@@ -429,6 +432,7 @@ int wv_set_gaussian_source(wv_ctx *c, int K, const float *mu, const float *sigma
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->has_source = true;
     c->freq = freq;
+    fused_source_changed(c->fused);
     return WV_OK;
 }
 
@@ -571,8 +575,9 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
         HIPCHK(c, hipMemcpyAsync(c->d_cyl, c->h_cyl.data(), c->h_cyl.size() * sizeof(Cyl), hipMemcpyHostToDevice, c->stream));
 
     if (impl == WV_IMPL_FUSED) {
-        rc = fused_prepare(c->fused, c->d_frames, c->d_scratch[0], c->d_scratch[1], capture != 0, c->d_cyl,
-                           M > 0 ? c->h_cyl.data() : nullptr, M, 3 * nsteps, c->stream);
+        rc = fused_prepare(c->fused, c->d_frames, c->d_scratch[0], c->d_scratch[1], capture != 0,
+                           c->has_source ? c->d_G : nullptr, c->d_cyl, M > 0 ? c->h_cyl.data() : nullptr, M, 3 * nsteps,
+                           c->stream);
         if (rc) return fail(c, rc == 2 ? WV_ERR_INVALID : WV_ERR_HIP, "fused_prepare failed");
         if (fused_generation(c->fused) != c->elast_generation) c->elast_valid = false;
         c->elast_generation = fused_generation(c->fused);
@@ -778,6 +783,7 @@ int wv_device_source_shape(wv_ctx *c, void **dptr, size_t *bytes)
     if (!dptr) return fail(c, WV_ERR_INVALID, "wv_device_source_shape: NULL");
     *dptr = c->d_G;
     if (bytes) *bytes = c->P * sizeof(float);
+    fused_source_changed(c->fused);  // the caller may write through the pointer
     return WV_OK;
 }
 

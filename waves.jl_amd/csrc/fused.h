@@ -33,9 +33,11 @@ int fused_generation(const FusedPlan *p);
 void fused_dump_stamps(FusedPlan *p, hipStream_t s);  // diagnostic, no-op unless WAVES_AMD_STAMPS is set
 // Called once per wv_integrate before the first step: d_table = device cylinder table (rows x M), h_table its host copy.
 // frames = env.wave (3 states, the last one is the initial condition), scratch0/1 the two ping-pong states.
-int fused_prepare(FusedPlan *p, float *frames, float *scratch0, float *scratch1, bool capture, const Cyl *d_table,
-                  const Cyl *h_table, int M, int rows, hipStream_t s);
+// G = device source shape or nullptr (NoSource).
+int fused_prepare(FusedPlan *p, float *frames, float *scratch0, float *scratch1, bool capture, const float *G,
+                  const Cyl *d_table, const Cyl *h_table, int M, int rows, hipStream_t s);
+void fused_source_changed(FusedPlan *p);  // the source shape was replaced
 void fused_launch(FusedPlan *p, const FusedStep &st, hipStream_t s);
-void fused_variant_counts(const FusedPlan *p, int out[3]);  // tiles per variant: FAST, MID, GEN
+void fused_variant_counts(const FusedPlan *p, int out[4]);  // tiles per field set: NONE, PX, PY, ALL
 
 }  // namespace wv

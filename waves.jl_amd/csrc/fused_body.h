@@ -12,17 +12,23 @@
 //             shrinking set of rows a stage still needs is spread evenly over the waves
 //   stage s : k_s is formed on the region shrunk by s cells; its inputs y_s are needed one cell further out
 //   LDS     : the three fields whose NEIGHBOURS a stage reads (W = U + f, Vx, Vy), as (total, incident) pairs so one
-//             ds_read_b64 serves both wave sets; Psi_x, Psi_y, Omega, u and the RK accumulator never leave registers
+//             ds_read_b64 serves both wave sets; everything else (u, the RK accumulator, the PML auxiliaries) stays in
+//             registers for the whole step
 //
-// Variants (block-uniform, chosen per tile on the host)
-//   FAST <PML=0, EDGE=0> : sigma_x = sigma_y = 0 over the region, region strictly inside the domain, auxiliary fields
-//                          zero there (they then stay exactly zero: d(Psi) = b*sigma*(..) = 0).  Six fields instead of
-//                          twelve; every dropped term is an exact "+0" / "-0*x" of the reference expression.
-//   MID  <PML=1, EDGE=0> : full equations, region strictly inside the domain.
-//   GEN  <PML=1, EDGE=1> : full equations, one-sided boundary stencils and the Dirichlet mask.  Valid for any tile.
-//   Non-EDGE variants publish P = cp*v instead of v:  cm*v[i-1] + cp*v[i+1]  ==  (cp*v[i+1]) - (cp*v[i-1])  bit for
-//   bit because cm == -cp exactly (both are +-1/(2D) rounded) and a + (-b) == a - b; one multiply per cell and field
-//   instead of two per derivative.
+// Field sets (template parameter AUX, block-uniform, chosen per tile on the host).  A PML auxiliary field whose
+// damping coefficient is zero over the tile's region stays exactly zero when it starts at zero
+// (dPsi_x = b*sigma_x*Vyy, dPsi_y = b*sigma_y*Vxx, dOmega = sigma_x*sigma_y*U), so a tile only carries the fields that
+// can be non-zero there; every term dropped from src/dynamics.jl:169-174 is an exact "+0", "-0*x" or "sigma+0":
+//   AUX_NONE  sigma_x = sigma_y = 0 : U, Vx, Vy                      (6 of 12 planes)   the interior: ~70 % of 700^2
+//   AUX_PX    sigma_y = 0           : U, Vx, Vy, Psi_x               (8 planes)         left / right PML bands
+//   AUX_PY    sigma_x = 0           : U, Vx, Vy, Psi_y               (8 planes)         bottom / top PML bands
+//   AUX_ALL                         : all six                        (12 planes)        corners; always valid
+//
+// Derivatives.  LDS holds P = cp*v, not v:  cm*v[i-1] + cp*v[i+1]  ==  (cp*v[i+1]) - (cp*v[i-1])  bit for bit, because
+// cm == -cp exactly (both are +-1/(2D) rounded) and a + (-b) == a - b: one multiply per cell and field instead of two
+// per derivative.  Tiles that touch the domain boundary additionally publish the RAW values of the three cells next
+// to that boundary into small side buffers, from which the boundary cell forms the reference's one-sided stencil
+// (src/operators.jl:14-15) and then applies the Dirichlet mask (src/dims.jl:117-124).
 #pragma once
 #include "types.h"
 
@@ -32,27 +38,31 @@ constexpr int FT_X = 64;         // region width
 constexpr int FT_H = 4;          // halo = number of RK stages
 constexpr int FT_LX = FT_X + 2;  // LDS row length: one guard cell each side, so lanes 0 / 63 read x-1 / x+1 unbranched
 
-enum : int { VAR_FAST = 0, VAR_MID = 1, VAR_GEN = 2 };
+enum : int { AUX_NONE = 0, AUX_PX = 1, AUX_PY = 2, AUX_ALL = 3 };
+enum : int { EDGE_L = 1, EDGE_R = 2, EDGE_T = 4, EDGE_B = 8 };  // region contains gx = 0 / nx-1 / gy = 0 / ny-1
 
 struct TileDesc {
     int x0, y0;      // first output cell (global indices)
     int ox, oy;      // output extent, ox <= 56, oy <= RY - 8
-    int variant;     // VAR_*
+    int aux;         // AUX_*
+    int edge;        // EDGE_* bits
     int cyl_begin;   // slice of FusedParams::cyl_idx with the cylinders that can touch the region ...
     int cyl_count;   // ... or -1: test all M cylinders
-    int slot;        // row of the energy-partial array (natural tile order: the reduction order never depends on
-                     // the launch order)
+    int slot;        // natural tile index: row of the energy-partial array and of src_flags (the reduction order
+                     // never depends on the launch order)
+    int pad;
 };
 
 struct FusedParams {
     int nx, ny;
-    size_t P;
+    unsigned P;       // nx*ny (12*P < 2^31, checked at create: 32-bit element offsets everywhere)
     Ops ops;
     const float *x, *y, *sx, *sy;
     float c0, c0sq;
     const float *u;   // state at the start of the step
     float *out;       // state at the end of the step
     const float *G;   // source shape or nullptr (NoSource)
+    const unsigned char *src_flags;  // per tile slot: shape != 0 somewhere in the region (nullptr: assume yes)
     float sfac[3];    // sin(2f0*pi*t*freq) at t, t + dt/2, t + dt
     const Cyl *cyl;   // 3 rows of M cylinders: stage times t, t + dt/2, t + dt
     int M;
@@ -65,45 +75,61 @@ struct FusedParams {
     unsigned long long *stamps;  // diagnostic: [ntiles][16] shader-clock stamps per phase, or nullptr (normal runs)
 };
 
-// LDS image of one tile: three (RY + 2) x FT_LX arrays of (total, incident) pairs carved out of one raw buffer (the
-// kernel instantiates variants with different RY over the same allocation).
+// LDS image of one tile, carved out of one raw buffer (the kernel instantiates field sets with different RY over the
+// same allocation): three (RY + 2) x FT_LX arrays of (total, incident) pairs, then the boundary side buffers.
+constexpr int FT_MAXCYL = 32;    // cylinders of one tile staged in LDS (more: read from global memory)
+
 struct FusedLds {
     F2 *W, *Vx, *Vy;
+    F2 *XL, *XR;  // [row][3 cells][W, Vx]   raw values at gx = 0,1,2 / nx-3,nx-2,nx-1
+    F2 *YT, *YB;  // [3 rows][lane][W, Vy]   raw values at gy = 0,1,2 / ny-3,ny-2,ny-1
+    Cyl *cyl;     // [3 stage times][cyl_count] the tile's culled cylinders
 };
-constexpr int lds_elems(int RY) { return 3 * (RY + 2) * FT_LX; }
-WV_HD FusedLds lds_view(F2 *raw, int RY)
+constexpr int lds_main_elems(int RY) { return 3 * (RY + 2) * FT_LX; }
+constexpr int lds_side_elems(int RYMAX) { return 2 * RYMAX * 6 + 2 * 3 * FT_X * 2; }
+constexpr int lds_elems(int RYMAX) { return lds_main_elems(RYMAX) + lds_side_elems(RYMAX) + 3 * FT_MAXCYL * 2; }
+WV_HD FusedLds lds_view(F2 *raw, int RY, int RYMAX)
 {
-    return FusedLds{raw, raw + (RY + 2) * FT_LX, raw + 2 * (RY + 2) * FT_LX};
+    F2 *side = raw + lds_main_elems(RYMAX);
+    return FusedLds{raw, raw + (RY + 2) * FT_LX, raw + 2 * (RY + 2) * FT_LX,
+                    side, side + RYMAX * 6, side + 2 * RYMAX * 6, side + 2 * RYMAX * 6 + 3 * FT_X * 2,
+                    reinterpret_cast<Cyl *>(side + lds_side_elems(RYMAX))};
 }
 
 WV_HD int lds_at(int lx, int ly) { return (ly + 1) * FT_LX + (lx + 1); }
 
-template <bool PML, int RPT>
+constexpr int aux_ns(int AUX) { return AUX == AUX_NONE ? 3 : (AUX == AUX_ALL ? 6 : 4); }
+// state plane (within one wave set) of local field j
+constexpr int aux_plane(int AUX, int j) { return j < 3 ? j : (AUX == AUX_PX ? 3 : (AUX == AUX_PY ? 4 : j)); }
+
+template <int AUX, int RPT>
 struct FusedRegs {
-    static constexpr int NS = PML ? 6 : 3;  // fields per wave set: U, Vx, Vy [, Psi_x, Psi_y, Omega]
+    static constexpr int NS = aux_ns(AUX);  // fields per wave set: U, Vx, Vy [, Psi_x | Psi_y | Psi_x, Psi_y, Omega]
     float u[RPT][2][NS];    // state at the start of the step
-    float acc[RPT][2][NS];  // k1 + 2k2 + 2k3 (+ k4)
-    float y[RPT][2][NS];    // input of the current stage; after stage 4 the new state
+    float acc[RPT][2][NS];  // k1 + 2k2 + 2k3
+    float y[RPT][2][NS];    // input of stages 2..4; after stage 4 the new state
     float g[RPT];           // source shape at the cell
     float b[RPT];           // c^2 of the total set at the current stage time
-    float sy[RPT];          // sigma_y of the row
-    float ys[RPT];          // y coordinate of the row
-    float sx, xs;           // sigma_x / x coordinate of the column
+    float sx;               // sigma_x of the column
+    float xs;               // x coordinate of the column (tiles with cylinders only)
 };
 
 WV_HD int stage_q(int S) { return S == 1 ? 0 : (S == 4 ? 2 : 1); }  // which of the three stage times a stage uses
 
 // speed(design, grid, c0) at one cell from the tile's culled cylinder list (culled cylinders would add an exact 0).
-// src/designs.jl:99-116.  No FMA may be formed here (-ffp-contract=off).
-WV_HD float tile_speed(const FusedParams &p, const TileDesc &t, int q, float x, float y)
+// src/designs.jl:99-116.  No FMA may be formed here (-ffp-contract=off).  The list is read from the LDS copy made by
+// fused_load (one broadcast ds_read_b128 per cylinder) or, for tiles with more than FT_MAXCYL cylinders, from global.
+WV_HD bool tile_cyl_in_lds(const TileDesc &t) { return t.cyl_count > 0 && t.cyl_count <= FT_MAXCYL; }
+
+WV_HD float tile_speed(const FusedParams &p, const TileDesc &t, const FusedLds &lds, int q, float x, float y)
 {
+    const bool staged = tile_cyl_in_lds(t);
     const Cyl *row = p.cyl + (size_t)q * p.M;
     const int n = t.cyl_count < 0 ? p.M : t.cyl_count;
     int count = 0;
     float cd = 0.0f;
     for (int k = 0; k < n; ++k) {
-        const int m = t.cyl_count < 0 ? k : p.cyl_idx[t.cyl_begin + k];
-        const Cyl c = row[m];
+        const Cyl c = staged ? lds.cyl[q * t.cyl_count + k] : row[t.cyl_count < 0 ? k : p.cyl_idx[t.cyl_begin + k]];
         const float ddx = x - c.px;
         const float ddy = y - c.py;
         const float d2 = ddx * ddx + ddy * ddy;
@@ -115,96 +141,115 @@ WV_HD float tile_speed(const FusedParams &p, const TileDesc &t, int q, float x, 
     return C0 + cd;
 }
 
-// ---- phase 0: global -> registers ---------------------------------------------------------------------------
-template <bool PML, bool EDGE, int NW, int RPT>
-WV_HD void fused_load(const FusedParams &p, const TileDesc &t, int tid, FusedRegs<PML, RPT> &r)
+WV_HD bool tile_has_src(const FusedParams &p, const TileDesc &t)
 {
-    constexpr int NS = FusedRegs<PML, RPT>::NS;
+    return p.G != nullptr && (p.src_flags == nullptr || p.src_flags[t.slot] != 0);
+}
+
+// ---- phase 0: global -> registers ---------------------------------------------------------------------------
+template <int AUX, int NW, int RPT>
+WV_HD void fused_load(const FusedParams &p, const TileDesc &t, int tid, const FusedLds &lds, FusedRegs<AUX, RPT> &r)
+{
+    constexpr int NS = aux_ns(AUX);
     const int lane = tid & 63, w = tid >> 6;
     const int gx = t.x0 - FT_H + lane;
     const bool inx = gx >= 0 && gx < p.nx;
     const int cgx = gx < 0 ? 0 : (gx >= p.nx ? p.nx - 1 : gx);
-    r.xs = p.x[cgx];
-    r.sx = PML ? p.sx[cgx] : 0.0f;
+    const bool has_src = tile_has_src(p, t);
+    r.sx = (AUX == AUX_PX || AUX == AUX_ALL) ? p.sx[cgx] : 0.0f;
+    r.xs = 0.0f;
+    if (p.M > 0 && t.cyl_count != 0) {  // block-uniform
+        r.xs = p.x[cgx];
+        // stage the culled cylinders of the three stage times in LDS; first read after the first barrier of stage 1
+        if (tile_cyl_in_lds(t) && tid < 3 * t.cyl_count)
+            lds.cyl[tid] = p.cyl[(size_t)(tid / t.cyl_count) * p.M + p.cyl_idx[t.cyl_begin + tid % t.cyl_count]];
+    }
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
         const int ly = w + NW * rr;
         const int gy = t.y0 - FT_H + ly;
         const bool in = inx && gy >= 0 && gy < p.ny && ly < t.oy + 2 * FT_H;
         const int cgy = gy < 0 ? 0 : (gy >= p.ny ? p.ny - 1 : gy);
-        const size_t id = (size_t)cgy * p.nx + cgx;
-        r.ys[rr] = p.y[cgy];
-        r.sy[rr] = PML ? p.sy[cgy] : 0.0f;
-        r.g[rr] = (p.G && in) ? p.G[id] : 0.0f;
+        const unsigned id = (unsigned)cgy * (unsigned)p.nx + (unsigned)cgx;
+        r.g[rr] = (has_src && in) ? p.G[id] : 0.0f;
         r.b[rr] = p.c0sq;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
-                const float v = in ? p.u[(size_t)(6 * s + j) * p.P + id] : 0.0f;
-                r.u[rr][s][j] = v;
-                r.y[rr][s][j] = v;
-                r.acc[rr][s][j] = 0.0f;
+                const float *plane = p.u + (size_t)(6 * s + aux_plane(AUX, j)) * p.P;
+                r.u[rr][s][j] = in ? plane[id] : 0.0f;
             }
     }
 }
 
 // ---- phase "publish": the stage input's stencil fields -> LDS ------------------------------------------------
-template <bool PML, bool EDGE, int NW, int RPT, int S>
+template <int AUX, int NW, int RPT, int S>
 WV_HD void fused_publish(const FusedParams &p, const TileDesc &t, int tid, const FusedLds &lds,
-                         const FusedRegs<PML, RPT> &r)
+                         const FusedRegs<AUX, RPT> &r)
 {
     const int lane = tid & 63, w = tid >> 6;
     const int rows = t.oy + 2 * FT_H;
     const float sf = p.sfac[stage_q(S)];
     const float cp = p.ops.cp;
+    const bool has_src = tile_has_src(p, t);
+    const int gx = t.x0 - FT_H + lane;
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
         const int ly = w + NW * rr;
         if (ly < S - 1 || ly >= rows - (S - 1)) continue;  // y_S is only needed on the region shrunk by S-1
-        const float f = r.g[rr] * sf;                      // shape .* sin(...)      src/sources.jl:67-69
-        const float wt = r.y[rr][0][0] + f;                // U .+ f                 src/dynamics.jl:166-167
-        const float wi = r.y[rr][1][0] + f;
+        const float(&yin)[2][aux_ns(AUX)] = S == 1 ? r.u[rr] : r.y[rr];
+        float wt = yin[0][0], wi = yin[1][0];
+        if (has_src) {
+            const float f = r.g[rr] * sf;  // shape .* sin(...)      src/sources.jl:67-69
+            wt = wt + f;                   // U .+ f                 src/dynamics.jl:166-167
+            wi = wi + f;
+        }
         const int i = lds_at(lane, ly);
-        if (EDGE) {
-            lds.W[i] = F2{wt, wi};
-            lds.Vx[i] = F2{r.y[rr][0][1], r.y[rr][1][1]};
-            lds.Vy[i] = F2{r.y[rr][0][2], r.y[rr][1][2]};
-        } else {
-            lds.W[i] = F2{cp * wt, cp * wi};
-            lds.Vx[i] = F2{cp * r.y[rr][0][1], cp * r.y[rr][1][1]};
-            lds.Vy[i] = F2{cp * r.y[rr][0][2], cp * r.y[rr][1][2]};
+        lds.W[i] = F2{cp * wt, cp * wi};
+        lds.Vx[i] = F2{cp * yin[0][1], cp * yin[1][1]};
+        lds.Vy[i] = F2{cp * yin[0][2], cp * yin[1][2]};
+        if (t.edge) {  // block-uniform: raw copies of the three cells next to a domain boundary
+            const int gy = t.y0 - FT_H + ly;
+            if ((t.edge & EDGE_L) && gx >= 0 && gx < 3) {
+                lds.XL[(ly * 3 + gx) * 2 + 0] = F2{wt, wi};
+                lds.XL[(ly * 3 + gx) * 2 + 1] = F2{yin[0][1], yin[1][1]};
+            }
+            if ((t.edge & EDGE_R) && gx >= p.nx - 3 && gx < p.nx) {
+                lds.XR[(ly * 3 + (gx - (p.nx - 3))) * 2 + 0] = F2{wt, wi};
+                lds.XR[(ly * 3 + (gx - (p.nx - 3))) * 2 + 1] = F2{yin[0][1], yin[1][1]};
+            }
+            if ((t.edge & EDGE_T) && gy >= 0 && gy < 3) {
+                lds.YT[(gy * FT_X + lane) * 2 + 0] = F2{wt, wi};
+                lds.YT[(gy * FT_X + lane) * 2 + 1] = F2{yin[0][2], yin[1][2]};
+            }
+            if ((t.edge & EDGE_B) && gy >= p.ny - 3 && gy < p.ny) {
+                lds.YB[((gy - (p.ny - 3)) * FT_X + lane) * 2 + 0] = F2{wt, wi};
+                lds.YB[((gy - (p.ny - 3)) * FT_X + lane) * 2 + 1] = F2{yin[0][2], yin[1][2]};
+            }
         }
     }
 }
 
-// `grad * v` along one LDS axis at an edge-aware cell (src/operators.jl:10-22,45-46); st = index stride of the axis
-WV_HD F2 edge_deriv(const Ops &o, const F2 *v, int i, int st, int g, int n)
+// one-sided rows of `grad` (src/operators.jl:14-15) on three raw (total, incident) pairs, ascending column order
+WV_HD F2 one_sided(float c0, float c1, float c2, F2 v0, F2 v1, F2 v2)
 {
-    F2 d;
-    if (g == 0) {
-        d.x = (o.f0 * v[i].x + o.f1 * v[i + st].x) + o.f2 * v[i + 2 * st].x;
-        d.y = (o.f0 * v[i].y + o.f1 * v[i + st].y) + o.f2 * v[i + 2 * st].y;
-    } else if (g == n - 1) {
-        d.x = (o.b0 * v[i - 2 * st].x + o.b1 * v[i - st].x) + o.b2 * v[i].x;
-        d.y = (o.b0 * v[i - 2 * st].y + o.b1 * v[i - st].y) + o.b2 * v[i].y;
-    } else {
-        d.x = o.cm * v[i - st].x + o.cp * v[i + st].x;
-        d.y = o.cm * v[i - st].y + o.cp * v[i + st].y;
-    }
-    return d;
+    return F2{(c0 * v0.x + c1 * v1.x) + c2 * v2.x, (c0 * v0.y + c1 * v1.y) + c2 * v2.y};
 }
 
 // ---- phase "compute": k_S from the LDS image, then the RK update of the registers ----------------------------
-template <bool PML, bool EDGE, int NW, int RPT, int S>
+template <int AUX, int NW, int RPT, int S>
 WV_HD void fused_compute(const FusedParams &p, const TileDesc &t, int tid, const FusedLds &lds,
-                         FusedRegs<PML, RPT> &r)
+                         FusedRegs<AUX, RPT> &r)
 {
-    constexpr int NS = FusedRegs<PML, RPT>::NS;
+    constexpr int NS = aux_ns(AUX);
+    constexpr bool HAS_SX = AUX == AUX_PX || AUX == AUX_ALL;
+    constexpr bool HAS_SY = AUX == AUX_PY || AUX == AUX_ALL;
     const int lane = tid & 63, w = tid >> 6;
     const int rows = t.oy + 2 * FT_H;
     const int gx = t.x0 - FT_H + lane;
     const bool has_cyl = p.M > 0 && t.cyl_count != 0;
+    const Ops &o = p.ops;
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
         const int ly = w + NW * rr;
@@ -212,51 +257,65 @@ WV_HD void fused_compute(const FusedParams &p, const TileDesc &t, int tid, const
         const int gy = t.y0 - FT_H + ly;
         if (gy < 0 || gy >= p.ny) continue;
         const int i = lds_at(lane, ly);
-        F2 Ux, Uy, Vxx, Vyy;
-        if (EDGE) {
-            // lanes outside the domain only produce values nobody reads; keep their LDS indices inside the row
-            const int gxe = (gx < 0 || gx >= p.nx) ? 1 : gx;
-            Ux = edge_deriv(p.ops, lds.W, i, 1, gxe, p.nx);
-            Uy = edge_deriv(p.ops, lds.W, i, FT_LX, gy, p.ny);
-            Vxx = edge_deriv(p.ops, lds.Vx, i, 1, gxe, p.nx);
-            Vyy = edge_deriv(p.ops, lds.Vy, i, FT_LX, gy, p.ny);
-        } else {
-            const F2 Wl = lds.W[i - 1], Wr = lds.W[i + 1], Wd = lds.W[i - FT_LX], Wu = lds.W[i + FT_LX];
-            const F2 Xl = lds.Vx[i - 1], Xr = lds.Vx[i + 1], Yd = lds.Vy[i - FT_LX], Yu = lds.Vy[i + FT_LX];
-            Ux = F2{Wr.x - Wl.x, Wr.y - Wl.y};
-            Uy = F2{Wu.x - Wd.x, Wu.y - Wd.y};
-            Vxx = F2{Xr.x - Xl.x, Xr.y - Xl.y};
-            Vyy = F2{Yu.x - Yd.x, Yu.y - Yd.y};
+        const F2 Wl = lds.W[i - 1], Wr = lds.W[i + 1], Wd = lds.W[i - FT_LX], Wu = lds.W[i + FT_LX];
+        const F2 Xl = lds.Vx[i - 1], Xr = lds.Vx[i + 1], Yd = lds.Vy[i - FT_LX], Yu = lds.Vy[i + FT_LX];
+        F2 Ux = F2{Wr.x - Wl.x, Wr.y - Wl.y};
+        F2 Uy = F2{Wu.x - Wd.x, Wu.y - Wd.y};
+        F2 Vxx = F2{Xr.x - Xl.x, Xr.y - Xl.y};
+        F2 Vyy = F2{Yu.x - Yd.x, Yu.y - Yd.y};
+        bool border = false;
+        if (t.edge) {  // block-uniform
+            if ((t.edge & EDGE_L) && gx == 0) {
+                const F2 *v = lds.XL + ly * 6;
+                Ux = one_sided(o.f0, o.f1, o.f2, v[0], v[2], v[4]);
+                Vxx = one_sided(o.f0, o.f1, o.f2, v[1], v[3], v[5]);
+            }
+            if ((t.edge & EDGE_R) && gx == p.nx - 1) {
+                const F2 *v = lds.XR + ly * 6;
+                Ux = one_sided(o.b0, o.b1, o.b2, v[0], v[2], v[4]);
+                Vxx = one_sided(o.b0, o.b1, o.b2, v[1], v[3], v[5]);
+            }
+            if ((t.edge & EDGE_T) && gy == 0) {
+                const F2 *v = lds.YT + lane * 2;
+                Uy = one_sided(o.f0, o.f1, o.f2, v[0], v[2 * FT_X], v[4 * FT_X]);
+                Vyy = one_sided(o.f0, o.f1, o.f2, v[1], v[2 * FT_X + 1], v[4 * FT_X + 1]);
+            }
+            if ((t.edge & EDGE_B) && gy == p.ny - 1) {
+                const F2 *v = lds.YB + lane * 2;
+                Uy = one_sided(o.b0, o.b1, o.b2, v[0], v[2 * FT_X], v[4 * FT_X]);
+                Vyy = one_sided(o.b0, o.b1, o.b2, v[1], v[2 * FT_X + 1], v[4 * FT_X + 1]);
+            }
+            border = gx <= 0 || gy == 0 || gx >= p.nx - 1 || gy == p.ny - 1;
         }
         if (S != 3 && has_cyl) {  // stage 3 shares t + dt/2 with stage 2
-            const float c = tile_speed(p, t, stage_q(S), r.xs, r.ys[rr]);  // C(t)   src/env.jl:99
-            r.b[rr] = c * c;                                               // c .^ 2 src/dynamics.jl:159
+            const float c = tile_speed(p, t, lds, stage_q(S), r.xs, p.y[gy]);  // C(t)   src/env.jl:99
+            r.b[rr] = c * c;                                                  // c .^ 2 src/dynamics.jl:159
         }
+        const float(&yin)[2][NS] = S == 1 ? r.u[rr] : r.y[rr];
+        const float sx = r.sx;
+        const float sy = HAS_SY ? p.sy[gy] : 0.0f;
         float k[2][NS];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const float b = s == 0 ? r.b[rr] : p.c0sq;
             const float ux = s == 0 ? Ux.x : Ux.y, uy = s == 0 ? Uy.x : Uy.y;
             const float vxx = s == 0 ? Vxx.x : Vxx.y, vyy = s == 0 ? Vyy.x : Vyy.y;
-            if (PML) {
-                const float sx = r.sx, sy = r.sy[rr];
-                const float U = r.y[rr][s][0];
-                // src/dynamics.jl:169-174, left to right as written
-                float dU = (((b * (vxx + vyy) + r.y[rr][s][3]) + r.y[rr][s][4]) - (sx + sy) * U) - r.y[rr][s][5];
-                if (EDGE) {
-                    const float bcv = (gx <= 0 || gy == 0 || gx >= p.nx - 1 || gy == p.ny - 1) ? 0.0f : 1.0f;
-                    dU = bcv * dU;  // bc .* dU   src/dynamics.jl:176, src/dims.jl:117-124
-                }
-                k[s][0] = dU;
-                k[s][1] = ux - sx * r.y[rr][s][1];
-                k[s][2] = uy - sy * r.y[rr][s][2];
+            const float U = yin[s][0];
+            // src/dynamics.jl:169-174, left to right as written, with the exact zeros of the field set dropped
+            float dU = b * (vxx + vyy);
+            if (AUX == AUX_PX) dU = (dU + yin[s][3]) - sx * U;
+            if (AUX == AUX_PY) dU = (dU + yin[s][3]) - sy * U;
+            if (AUX == AUX_ALL) dU = (((dU + yin[s][3]) + yin[s][4]) - (sx + sy) * U) - yin[s][5];
+            if (border) dU = 0.0f * dU;  // bc .* dU   src/dynamics.jl:176, src/dims.jl:117-124
+            k[s][0] = dU;
+            k[s][1] = HAS_SX ? ux - sx * yin[s][1] : ux;
+            k[s][2] = HAS_SY ? uy - sy * yin[s][2] : uy;
+            if (AUX == AUX_PX) k[s][3] = (b * sx) * vyy;
+            if (AUX == AUX_PY) k[s][3] = (b * sy) * vxx;
+            if (AUX == AUX_ALL) {
                 k[s][3] = (b * sx) * vyy;
                 k[s][4] = (b * sy) * vxx;
                 k[s][5] = (sx * sy) * U;
-            } else {
-                k[s][0] = b * (vxx + vyy);
-                k[s][1] = ux;
-                k[s][2] = uy;
             }
         }
         // src/dynamics.jl:9-16 and :41
@@ -283,10 +342,10 @@ WV_HD void fused_compute(const FusedParams &p, const TileDesc &t, int tid, const
 }
 
 // ---- last phase: registers -> global, energy terms of src/env.jl:105-111 --------------------------------------
-template <bool PML, bool EDGE, int NW, int RPT>
-WV_HD void fused_store(const FusedParams &p, const TileDesc &t, int tid, const FusedRegs<PML, RPT> &r, float e[3])
+template <int AUX, int NW, int RPT>
+WV_HD void fused_store(const FusedParams &p, const TileDesc &t, int tid, const FusedRegs<AUX, RPT> &r, float e[3])
 {
-    constexpr int NS = FusedRegs<PML, RPT>::NS;
+    constexpr int NS = aux_ns(AUX);
     const int lane = tid & 63, w = tid >> 6;
     e[0] = e[1] = e[2] = 0.0f;
     if (lane < FT_H || lane >= FT_H + t.ox) return;
@@ -296,11 +355,14 @@ WV_HD void fused_store(const FusedParams &p, const TileDesc &t, int tid, const F
         const int ly = w + NW * rr;
         if (ly < FT_H || ly >= FT_H + t.oy) continue;
         const int gy = t.y0 - FT_H + ly;
-        const size_t id = (size_t)gy * p.nx + gx;
+        const unsigned id = (unsigned)gy * (unsigned)p.nx + (unsigned)gx;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int j = 0; j < NS; ++j) p.out[(size_t)(6 * s + j) * p.P + id] = r.y[rr][s][j];
+            for (int j = 0; j < NS; ++j) {
+                float *plane = p.out + (size_t)(6 * s + aux_plane(AUX, j)) * p.P;
+                plane[id] = r.y[rr][s][j];
+            }
         const float ut = r.y[rr][0][0], ui = r.y[rr][1][0], us = ut - ui;
         e[0] += ut * ut;
         e[1] += ui * ui;

@@ -12,15 +12,15 @@ namespace wv {
 
 struct HostPlan {
     int nx = 0, ny = 0;
-    int RYF = 0, RYP = 0;           // region rows of FAST tiles / of MID and GEN tiles
+    int RYF = 0, RYB = 0, RYP = 0;  // region rows of AUX_NONE tiles / AUX_PX+AUX_PY tiles / AUX_ALL tiles
     std::vector<TileDesc> tiles;    // launch order (see plan_order)
-    int count[3] = {0, 0, 0};       // tiles per variant
+    int count[4] = {0, 0, 0, 0};    // tiles per field set
     bool monotonic = true;          // x[] and y[] strictly increasing (needed for bounding-box culling)
 };
 
 // n cells starting at `first` in pieces of at most omax, sizes differing by at most one (never a sliver: a run of
-// >= 5 cells cut into pieces of <= 8 keeps every piece >= 3, which the one-sided boundary stencil -- it reaches two
-// cells inward -- relies on).
+// >= 3 cells cut into pieces of <= omax >= 8 keeps every piece >= 3, which the one-sided boundary stencil -- it
+// reaches two cells inward -- relies on).
 inline void plan_split(int first, int n, int omax, std::vector<int> &start, std::vector<int> &len)
 {
     const int pieces = (n + omax - 1) / omax;
@@ -34,44 +34,79 @@ inline void plan_split(int first, int n, int omax, std::vector<int> &start, std:
     }
 }
 
-// clean[i]: a FAST tile may own output cell i along this axis -- every cell within the 4-cell halo is strictly inside
-// the domain and has sigma == 0 there.
-inline std::vector<char> plan_clean_axis(int n, const float *sig)
+// zero[i]: sigma == 0 at every cell within the 4-cell halo of output cell i (clipped to the domain), i.e. a tile
+// that owns cell i may drop the PML terms of this axis.
+inline std::vector<char> plan_axis_zero(int n, const float *sig)
 {
     std::vector<char> c(n, 0);
     for (int i = 0; i < n; ++i) {
-        bool ok = i - FT_H >= 1 && i + FT_H <= n - 2;
+        bool ok = true;
         for (int k = std::max(i - FT_H, 0); ok && k <= std::min(i + FT_H, n - 1); ++k) ok = sig[k] == 0.0f;
         c[i] = ok ? 1 : 0;
     }
     return c;
 }
 
+struct PlanRun {
+    int start, len;
+    bool zero;
+};
+
+// maximal runs of equal `zero`; a run shorter than 3 cells at either end of the axis is merged into its neighbour
+// (as non-zero) so that the piece holding a boundary cell is never a sliver
+inline std::vector<PlanRun> plan_runs(const std::vector<char> &zero)
+{
+    std::vector<PlanRun> runs;
+    const int n = (int)zero.size();
+    int j = 0;
+    while (j < n) {
+        int e = j;
+        while (e < n && zero[e] == zero[j]) ++e;
+        runs.push_back(PlanRun{j, e - j, zero[j] != 0});
+        j = e;
+    }
+    while (runs.size() > 1 && runs.front().len < 3) {
+        runs[1].start = runs[0].start;
+        runs[1].len += runs[0].len;
+        runs[1].zero = false;
+        runs.erase(runs.begin());
+    }
+    while (runs.size() > 1 && runs.back().len < 3) {
+        runs[runs.size() - 2].len += runs.back().len;
+        runs[runs.size() - 2].zero = false;
+        runs.pop_back();
+    }
+    return runs;
+}
+
 // Launch order.  Blocks are dealt round-robin over the 8 XCDs (block b and b + 8 share an L2: MI355X_MICROARCH.md,
 // "Workgroup dispatch"), so the tiles are cut into 8 spatially contiguous groups of equal estimated cost, and launch
 // position i takes the next tile of group i % 8: neighbouring tiles -- which re-read each other's halo rows, and
-// re-read next step what they wrote this step -- meet in the same L2.  Inside a group the expensive (12-field) tiles
-// go first so the cheap ones fill the tail.  Placement only affects speed, never results.
+// re-read next step what they wrote this step -- meet in the same L2.  Inside a group the expensive tiles go first
+// so the cheap ones fill the tail.  Placement only affects speed, never results.
+inline double plan_tile_cost(const TileDesc &t)
+{
+    const double cells = (double)(t.ox + 2 * FT_H) * (t.oy + 2 * FT_H);
+    return cells * (t.aux == AUX_NONE ? 1.0 : (t.aux == AUX_ALL ? 2.2 : 1.45)) * (t.edge ? 1.1 : 1.0);
+}
+
 inline void plan_order(std::vector<TileDesc> &natural, std::vector<TileDesc> &out, bool xcd_aware)
 {
-    auto cost = [](const TileDesc &t) {
-        const double cells = (double)(t.ox + 2 * FT_H) * (t.oy + 2 * FT_H);
-        return cells * (t.variant == VAR_FAST ? 1.0 : (t.variant == VAR_MID ? 2.4 : 2.8));
-    };
     out.clear();
     const int G = xcd_aware ? 8 : 1;
     double total = 0.0;
-    for (const TileDesc &t : natural) total += cost(t);
+    for (const TileDesc &t : natural) total += plan_tile_cost(t);
     std::vector<std::vector<TileDesc>> grp(G);
     double acc = 0.0;
     for (const TileDesc &t : natural) {
         int g = (int)(acc / (total / G + 1e-9));
         if (g >= G) g = G - 1;
         grp[g].push_back(t);
-        acc += cost(t);
+        acc += plan_tile_cost(t);
     }
     for (auto &g : grp)
-        std::stable_sort(g.begin(), g.end(), [](const TileDesc &a, const TileDesc &b) { return a.variant > b.variant; });
+        std::stable_sort(g.begin(), g.end(),
+                         [](const TileDesc &a, const TileDesc &b) { return plan_tile_cost(a) > plan_tile_cost(b); });
     std::vector<size_t> pos(G, 0);
     const size_t n = natural.size();
     for (size_t i = 0; out.size() < n; ++i) {
@@ -91,72 +126,68 @@ inline void plan_order(std::vector<TileDesc> &natural, std::vector<TileDesc> &ou
     }
 }
 
-// aux_zero: Psi_x, Psi_y, Omega are zero at every cell with sigma_x = sigma_y = 0 (and every state buffer is clean
-// there), so tiles wholly inside that zone may run the 6-field FAST variant -- with taller tiles (RYF rows), since a
-// FAST thread carries half the state of a MID/GEN thread.  Everything else is cut into RYP-row tiles.
-inline bool plan_build_tiles(HostPlan &pl, int nx, int ny, int RYF, int RYP, const float *x, const float *y,
-                             const float *sx, const float *sy, bool aux_zero, bool xcd_aware)
+// reduced: the state satisfies "Psi_x = 0 wherever sigma_x = 0, Psi_y = 0 wherever sigma_y = 0, Omega = 0 wherever
+// sigma_x*sigma_y = 0" (and every state buffer a step writes to holds zeros in the planes a reduced tile leaves out),
+// so tiles may carry reduced field sets -- and be taller, since a thread then carries less state per cell.  Otherwise
+// every tile is AUX_ALL.
+inline bool plan_build_tiles(HostPlan &pl, int nx, int ny, int RYF, int RYB, int RYP, const float *x, const float *y,
+                             const float *sx, const float *sy, bool reduced, bool xcd_aware)
 {
     pl.nx = nx;
     pl.ny = ny;
     pl.RYF = RYF;
+    pl.RYB = RYB;
     pl.RYP = RYP;
     pl.tiles.clear();
-    pl.count[0] = pl.count[1] = pl.count[2] = 0;
+    for (int &c : pl.count) c = 0;
     pl.monotonic = true;
     for (int i = 1; i < nx; ++i)
         if (!(x[i] > x[i - 1])) pl.monotonic = false;
     for (int j = 1; j < ny; ++j)
         if (!(y[j] > y[j - 1])) pl.monotonic = false;
-    const int OYF = RYF - 2 * FT_H, OYP = RYP - 2 * FT_H;
-    if (OYF < 3 || OYP < 3 || nx < 8 || ny < 8) return false;
+    const int OY[4] = {RYF - 2 * FT_H, RYB - 2 * FT_H, RYB - 2 * FT_H, RYP - 2 * FT_H};
+    if (OY[0] < 8 || OY[1] < 8 || OY[3] < 8 || nx < 8 || ny < 8) return false;
     std::vector<int> xs, xl;
     plan_split(0, nx, FT_X - 2 * FT_H, xs, xl);
     for (int l : xl)
         if (l < 3) return false;
-    const std::vector<char> cx = plan_clean_axis(nx, sx), cy = plan_clean_axis(ny, sy);
+    const std::vector<char> zx = plan_axis_zero(nx, sx), zy = plan_axis_zero(ny, sy);
+    const std::vector<PlanRun> runs = plan_runs(zy);
     std::vector<TileDesc> all;
     int slot = 0;
     for (size_t a = 0; a < xs.size(); ++a) {
-        bool strip_clean = aux_zero;
-        for (int i = xs[a]; i < xs[a] + xl[a]; ++i) strip_clean = strip_clean && cx[i];
-        // rows: maximal runs of equal cleanliness, each cut evenly
-        std::vector<int> ys, yl;
-        std::vector<char> tall;
-        int j = 0;
-        while (j < ny) {
-            int e = j;
-            while (e < ny && cy[e] == cy[j]) ++e;
-            const bool t = strip_clean && cy[j];
-            const size_t before = ys.size();
-            plan_split(j, e - j, t ? OYF : OYP, ys, yl);
-            tall.insert(tall.end(), ys.size() - before, t ? 1 : 0);
-            j = e;
-        }
-        for (size_t b = 0; b < ys.size(); ++b) {
-            TileDesc t{};
-            t.x0 = xs[a];
-            t.y0 = ys[b];
-            t.ox = xl[a];
-            t.oy = yl[b];
-            t.cyl_begin = 0;
-            t.cyl_count = 0;
-            t.slot = slot++;
-            const int rx0 = t.x0 - FT_H, rx1 = t.x0 + t.ox + FT_H - 1;  // region, inclusive
-            const int ry0 = t.y0 - FT_H, ry1 = t.y0 + t.oy + FT_H - 1;
-            const bool edge = rx0 <= 0 || ry0 <= 0 || rx1 >= nx - 1 || ry1 >= ny - 1;
-            bool pml = false;
-            for (int i = std::max(rx0, 0); i <= std::min(rx1, nx - 1); ++i)
-                if (sx[i] != 0.0f) pml = true;
-            for (int jj = std::max(ry0, 0); jj <= std::min(ry1, ny - 1); ++jj)
-                if (sy[jj] != 0.0f) pml = true;
-            t.variant = edge ? VAR_GEN : ((pml || !aux_zero) ? VAR_MID : VAR_FAST);
-            if (tall[b] && t.variant != VAR_FAST) return false;                  // cannot happen: see plan_clean_axis
-            if (t.oy > (t.variant == VAR_FAST ? OYF : OYP)) return false;
-            if ((t.x0 == 0 || t.x0 + t.ox == nx) && t.ox < 3) return false;      // boundary stencil reaches 2 inward
-            if ((t.y0 == 0 || t.y0 + t.oy == ny) && t.oy < 3) return false;
-            pl.count[t.variant]++;
-            all.push_back(t);
+        bool x_zero = reduced;
+        for (int i = xs[a]; i < xs[a] + xl[a]; ++i) x_zero = x_zero && zx[i];
+        for (const PlanRun &run : runs) {
+            const bool y_zero = reduced && run.zero;
+            const int aux = x_zero ? (y_zero ? AUX_NONE : AUX_PY) : (y_zero ? AUX_PX : AUX_ALL);
+            std::vector<int> ys, yl;
+            plan_split(run.start, run.len, OY[aux], ys, yl);
+            for (size_t b = 0; b < ys.size(); ++b) {
+                TileDesc t{};
+                t.x0 = xs[a];
+                t.y0 = ys[b];
+                t.ox = xl[a];
+                t.oy = yl[b];
+                t.aux = aux;
+                t.slot = slot++;
+                const int rx0 = t.x0 - FT_H, rx1 = t.x0 + t.ox + FT_H - 1;  // region, inclusive
+                const int ry0 = t.y0 - FT_H, ry1 = t.y0 + t.oy + FT_H - 1;
+                t.edge = (rx0 <= 0 ? EDGE_L : 0) | (rx1 >= nx - 1 ? EDGE_R : 0) | (ry0 <= 0 ? EDGE_T : 0) |
+                         (ry1 >= ny - 1 ? EDGE_B : 0);
+                // the field set must be consistent with the damping profile over the whole region
+                bool sx_zero = true, sy_zero = true;
+                for (int i = std::max(rx0, 0); i <= std::min(rx1, nx - 1); ++i) sx_zero = sx_zero && sx[i] == 0.0f;
+                for (int j = std::max(ry0, 0); j <= std::min(ry1, ny - 1); ++j) sy_zero = sy_zero && sy[j] == 0.0f;
+                if ((aux == AUX_NONE || aux == AUX_PY) && !sx_zero) return false;
+                if ((aux == AUX_NONE || aux == AUX_PX) && !sy_zero) return false;
+                if (aux != AUX_ALL && !reduced) return false;
+                if (t.oy > OY[aux] || t.ox > FT_X - 2 * FT_H) return false;
+                if ((t.x0 == 0 || t.x0 + t.ox == nx) && t.ox < 3) return false;  // boundary stencil reaches 2 inward
+                if ((t.y0 == 0 || t.y0 + t.oy == ny) && t.oy < 3) return false;
+                pl.count[aux]++;
+                all.push_back(t);
+            }
         }
     }
     plan_order(all, pl.tiles, xcd_aware);

@@ -17,12 +17,12 @@ namespace wv {
 
 namespace {
 
-template <bool PML, bool EDGE, int NW, int RPT>
+template <int AUX, int NW, int RPT, int RYMAX>
 __device__ __forceinline__ void run_tile(const FusedParams &p, const TileDesc &t, F2 *raw, float e[3])
 {
     const int tid = threadIdx.x;
-    const FusedLds lds = lds_view(raw, NW * RPT);
-    FusedRegs<PML, RPT> r;
+    const FusedLds lds = lds_view(raw, NW * RPT, RYMAX);
+    FusedRegs<AUX, RPT> r;
     // diagnostic stamps (p.stamps == nullptr in every normal run: one block-uniform branch per phase)
     unsigned long long *st = p.stamps ? p.stamps + (size_t)t.slot * 16 : nullptr;
 #define WV_STAMP(k)                                                     \
@@ -31,12 +31,13 @@ __device__ __forceinline__ void run_tile(const FusedParams &p, const TileDesc &t
         st[k] = __builtin_amdgcn_s_memtime();                           \
     }
     WV_STAMP(0)
-    fused_load<PML, EDGE, NW, RPT>(p, t, tid, r);
+    if (st && tid == 0) st[14] = __builtin_amdgcn_s_memrealtime();
+    fused_load<AUX, NW, RPT>(p, t, tid, lds, r);
 #define WV_STAGE(S)                                          \
-    fused_publish<PML, EDGE, NW, RPT, S>(p, t, tid, lds, r); \
+    fused_publish<AUX, NW, RPT, S>(p, t, tid, lds, r);      \
     __syncthreads();                                         \
     WV_STAMP(2 * S - 1)                                      \
-    fused_compute<PML, EDGE, NW, RPT, S>(p, t, tid, lds, r); \
+    fused_compute<AUX, NW, RPT, S>(p, t, tid, lds, r);      \
     if (S < 4) __syncthreads();                              \
     WV_STAMP(2 * S)
     WV_STAGE(1)
@@ -44,33 +45,36 @@ __device__ __forceinline__ void run_tile(const FusedParams &p, const TileDesc &t
     WV_STAGE(3)
     WV_STAGE(4)
 #undef WV_STAGE
-    fused_store<PML, EDGE, NW, RPT>(p, t, tid, r, e);
+    fused_store<AUX, NW, RPT>(p, t, tid, r, e);
     WV_STAMP(9)
     if (st && tid == 0) {
         st[10] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID, all 32 bits
         st[11] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
         st[12] = __builtin_amdgcn_s_memrealtime();
-        st[13] = (unsigned long long)t.variant;
+        st[13] = (unsigned long long)(t.aux | (t.edge << 4));
     }
 #undef WV_STAMP
 }
 
-// RF / RP: rows per thread of the 6-field FAST tiles / of the 12-field MID and GEN tiles (a FAST thread carries half
-// the state per cell, so it can own twice the cells at the same register budget).
-template <int NW, int RF, int RP>
-__global__ __launch_bounds__(NW * 64) void k_step_fused(FusedParams p)
+// RF / RB / RP: rows per thread of the AUX_NONE / AUX_PX+AUX_PY / AUX_ALL tiles (a thread of a reduced field set
+// carries less state per cell, so it owns more cells at the same register budget).
+template <int NW, int RF, int RB, int RP>
+__global__ __launch_bounds__(NW * 64, 4) void k_step_fused(FusedParams p)  // 4 waves/SIMD = 2 blocks per CU: <= 128 VGPRs
 {
-    constexpr int RYMAX = NW * (RF > RP ? RF : RP);
+    constexpr int RMAX = RF > RB ? (RF > RP ? RF : RP) : (RB > RP ? RB : RP);
+    constexpr int RYMAX = NW * RMAX;
     __shared__ F2 raw[lds_elems(RYMAX)];
     __shared__ float red[3][NW];
     const TileDesc t = p.tiles[blockIdx.x];
     float e[3];
-    if (t.variant == VAR_FAST)
-        run_tile<false, false, NW, RF>(p, t, raw, e);
-    else if (t.variant == VAR_MID)
-        run_tile<true, false, NW, RP>(p, t, raw, e);
+    if (t.aux == AUX_NONE)
+        run_tile<AUX_NONE, NW, RF, RYMAX>(p, t, raw, e);
+    else if (t.aux == AUX_PX)
+        run_tile<AUX_PX, NW, RB, RYMAX>(p, t, raw, e);
+    else if (t.aux == AUX_PY)
+        run_tile<AUX_PY, NW, RB, RYMAX>(p, t, raw, e);
     else
-        run_tile<true, true, NW, RP>(p, t, raw, e);
+        run_tile<AUX_ALL, NW, RP, RYMAX>(p, t, raw, e);
     if (p.epart) {  // block-uniform
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -88,7 +92,8 @@ __global__ __launch_bounds__(NW * 64) void k_step_fused(FusedParams p)
     }
 }
 
-// any non-zero auxiliary field (Psi_x, Psi_y, Omega of either set) at a cell with sigma_x = sigma_y = 0 ?
+// Does the state violate "Psi_x = 0 wherever sigma_x = 0, Psi_y = 0 wherever sigma_y = 0, Omega = 0 wherever
+// sigma_x*sigma_y = 0" ?  (the precondition of the reduced field sets)
 __global__ __launch_bounds__(256) void k_aux_check(const float *__restrict__ state, int nx, int ny, size_t P,
                                                    const float *__restrict__ sx, const float *__restrict__ sy,
                                                    int *__restrict__ flag)
@@ -96,33 +101,56 @@ __global__ __launch_bounds__(256) void k_aux_check(const float *__restrict__ sta
     bool bad = false;
     for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < P; q += (size_t)gridDim.x * 256) {
         const int i = (int)(q % nx), j = (int)(q / nx);
-        if (sx[i] == 0.0f && sy[j] == 0.0f) {
-#pragma unroll
-            for (int f : {3, 4, 5, 9, 10, 11}) bad = bad || (state[(size_t)f * P + q] != 0.0f);
-        }
+        const bool zx = sx[i] == 0.0f, zy = sy[j] == 0.0f;
+        if (zx) bad = bad || state[3 * P + q] != 0.0f || state[9 * P + q] != 0.0f;
+        if (zy) bad = bad || state[4 * P + q] != 0.0f || state[10 * P + q] != 0.0f;
+        if (zx || zy) bad = bad || state[5 * P + q] != 0.0f || state[11 * P + q] != 0.0f;
     }
     if (bad) atomicOr(flag, 1);
 }
 
-// zero the auxiliary planes at every cell with sigma_x = sigma_y = 0 (makes a buffer a valid FAST-tile target)
+// zero the planes a reduced tile would leave unwritten (makes a buffer a valid target of reduced tiles)
 __global__ __launch_bounds__(256) void k_aux_clean(float *__restrict__ state, int nx, int ny, size_t P,
                                                    const float *__restrict__ sx, const float *__restrict__ sy)
 {
     for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < P; q += (size_t)gridDim.x * 256) {
         const int i = (int)(q % nx), j = (int)(q / nx);
-        if (sx[i] == 0.0f && sy[j] == 0.0f) {
-#pragma unroll
-            for (int f : {3, 4, 5, 9, 10, 11}) state[(size_t)f * P + q] = 0.0f;
-        }
+        const bool zx = sx[i] == 0.0f, zy = sy[j] == 0.0f;
+        if (zx) state[3 * P + q] = state[9 * P + q] = 0.0f;
+        if (zy) state[4 * P + q] = state[10 * P + q] = 0.0f;
+        if (zx || zy) state[5 * P + q] = state[11 * P + q] = 0.0f;
     }
+}
+
+// flags[slot] = the source shape is non-zero somewhere in the tile's region (tiles without it skip the G loads and
+// the "U .+ f" adds: U + (+-0) == U exactly)
+__global__ __launch_bounds__(256) void k_src_flags(const TileDesc *__restrict__ tiles, const float *__restrict__ G,
+                                                   int nx, int ny, unsigned char *__restrict__ flags)
+{
+    const TileDesc t = tiles[blockIdx.x];
+    const int w = t.ox + 2 * FT_H, h = t.oy + 2 * FT_H;
+    bool any = false;
+    for (int q = threadIdx.x; q < w * h; q += 256) {
+        const int gx = t.x0 - FT_H + q % w, gy = t.y0 - FT_H + q / w;
+        if (gx >= 0 && gx < nx && gy >= 0 && gy < ny) any = any || G[(size_t)gy * nx + gx] != 0.0f;
+    }
+    __shared__ int s_any;
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    if (any) atomicOr(&s_any, 1);
+    __syncthreads();
+    if (threadIdx.x == 0) flags[t.slot] = s_any ? 1 : 0;
 }
 
 }  // namespace
 
 struct FusedPlan {
     Grid g{};
-    int NW = 8, RF = 4, RP = 2;   // rows per thread: FAST tiles / MID+GEN tiles
+    int NW = 8, RF = 4, RB = 3, RP = 2;  // rows per thread: AUX_NONE / AUX_PX, AUX_PY / AUX_ALL tiles
     bool xcd_aware = true;
+    unsigned char *d_src_flags = nullptr;
+    size_t src_flags_cap = 0;
+    bool src_dirty = true;        // the source shape (or the tiling) changed since the flags were computed
     std::vector<float> x, y, sx, sy;
     HostPlan hp;
     bool tiles_valid = false;
@@ -153,11 +181,15 @@ FusedPlan *fused_create(const Grid &g, const float *x, const float *y, const flo
     p->y.assign(y, y + g.ny);
     p->sx.assign(sx, sx + g.nx);
     p->sy.assign(sy, sy + g.ny);
-    if (const char *e = getenv("WAVES_AMD_FUSED_TILES")) {  // tuning knob: "RF,RP" in {4,2 | 3,2 | 3,3 | 2,2}
-        int a = 0, b = 0;
-        if (sscanf(e, "%d,%d", &a, &b) == 2 && ((a == 4 && b == 2) || (a == 3 && b == 2) || (a == 3 && b == 3) || (a == 2 && b == 2))) {
-            p->RF = a;
-            p->RP = b;
+    if (const char *e = getenv("WAVES_AMD_FUSED_TILES")) {  // tuning knob: "RF,RB,RP", see fused_launch for the set
+        int a = 0, b = 0, c = 0;
+        if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) {
+            const int key = a * 100 + b * 10 + c;
+            if (key == 432 || key == 332 || key == 322 || key == 222 || key == 333 || key == 422) {
+                p->RF = a;
+                p->RB = b;
+                p->RP = c;
+            }
         }
     }
     if (const char *e = getenv("WAVES_AMD_FUSED_XCD")) p->xcd_aware = atoi(e) != 0;
@@ -176,6 +208,7 @@ void fused_destroy(FusedPlan *p)
     if (p->d_idx) (void)hipFree(p->d_idx);
     if (p->d_flag) (void)hipFree(p->d_flag);
     if (p->d_stamps) (void)hipFree(p->d_stamps);
+    if (p->d_src_flags) (void)hipFree(p->d_src_flags);
     delete p;
 }
 
@@ -204,9 +237,10 @@ void fused_state_zeroed(FusedPlan *p)
 static bool ensure_tiles(FusedPlan *p, bool aux_zero)
 {
     if (p->tiles_valid && p->tiles_aux_zero == aux_zero) return true;
-    if (!plan_build_tiles(p->hp, p->g.nx, p->g.ny, p->NW * p->RF, p->NW * p->RP, p->x.data(), p->y.data(),
-                          p->sx.data(), p->sy.data(), aux_zero, p->xcd_aware))
+    if (!plan_build_tiles(p->hp, p->g.nx, p->g.ny, p->NW * p->RF, p->NW * p->RB, p->NW * p->RP, p->x.data(),
+                          p->y.data(), p->sx.data(), p->sy.data(), aux_zero, p->xcd_aware))
         return false;
+    p->src_dirty = true;
     p->tiles_valid = true;
     p->tiles_aux_zero = aux_zero;
     p->generation++;
@@ -219,8 +253,10 @@ int fused_energy_blocks(FusedPlan *p)
     return (int)p->hp.tiles.size();
 }
 
-int fused_prepare(FusedPlan *p, float *frames, float *scratch0, float *scratch1, bool capture, const Cyl *d_table,
-                  const Cyl *h_table, int M, int rows, hipStream_t s)
+void fused_source_changed(FusedPlan *p) { p->src_dirty = true; }
+
+int fused_prepare(FusedPlan *p, float *frames, float *scratch0, float *scratch1, bool capture, const float *G,
+                  const Cyl *d_table, const Cyl *h_table, int M, int rows, hipStream_t s)
 {
     const Grid &g = p->g;
     const size_t N = g.P * kFields;
@@ -272,6 +308,17 @@ int fused_prepare(FusedPlan *p, float *frames, float *scratch0, float *scratch1,
     if (!p->idx.empty() &&
         hipMemcpyAsync(p->d_idx, p->idx.data(), p->idx.size() * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess)
         return 1;
+    if (G && p->src_dirty) {
+        if (nt > p->src_flags_cap) {
+            if (p->d_src_flags) (void)hipFree(p->d_src_flags);
+            p->d_src_flags = nullptr;
+            p->src_flags_cap = 0;
+            if (hipMalloc((void **)&p->d_src_flags, nt) != hipSuccess) return 1;
+            p->src_flags_cap = nt;
+        }
+        hipLaunchKernelGGL(k_src_flags, dim3((unsigned)nt), dim3(256), 0, s, p->d_tiles, G, g.nx, g.ny, p->d_src_flags);
+        p->src_dirty = false;
+    }
     // the host vectors are reused by the next prepare: make sure the copies are done with them
     if (hipStreamSynchronize(s) != hipSuccess) return 1;
     p->d_table = d_table;
@@ -285,7 +332,7 @@ void fused_launch(FusedPlan *pl, const FusedStep &st, hipStream_t s)
     FusedParams p{};
     p.nx = g.nx;
     p.ny = g.ny;
-    p.P = g.P;
+    p.P = (unsigned)g.P;
     p.ops = g.ops;
     p.x = g.x;
     p.y = g.y;
@@ -296,6 +343,7 @@ void fused_launch(FusedPlan *pl, const FusedStep &st, hipStream_t s)
     p.u = st.u;
     p.out = st.out;
     p.G = st.G;
+    p.src_flags = st.G ? pl->d_src_flags : nullptr;
     p.sfac[0] = st.sfac[0];
     p.sfac[1] = st.sfac[1];
     p.sfac[2] = st.sfac[2];
@@ -319,12 +367,14 @@ void fused_launch(FusedPlan *pl, const FusedStep &st, hipStream_t s)
         p.stamps = pl->d_stamps;
     }
     const dim3 grid((unsigned)pl->hp.tiles.size());
-    const int key = pl->RF * 10 + pl->RP;
+    const int key = pl->RF * 100 + pl->RB * 10 + pl->RP;
     switch (key) {
-        case 32: hipLaunchKernelGGL((k_step_fused<8, 3, 2>), grid, dim3(512), 0, s, p); break;
-        case 33: hipLaunchKernelGGL((k_step_fused<8, 3, 3>), grid, dim3(512), 0, s, p); break;
-        case 22: hipLaunchKernelGGL((k_step_fused<8, 2, 2>), grid, dim3(512), 0, s, p); break;
-        default: hipLaunchKernelGGL((k_step_fused<8, 4, 2>), grid, dim3(512), 0, s, p); break;
+        case 332: hipLaunchKernelGGL((k_step_fused<8, 3, 3, 2>), grid, dim3(512), 0, s, p); break;
+        case 322: hipLaunchKernelGGL((k_step_fused<8, 3, 2, 2>), grid, dim3(512), 0, s, p); break;
+        case 222: hipLaunchKernelGGL((k_step_fused<8, 2, 2, 2>), grid, dim3(512), 0, s, p); break;
+        case 333: hipLaunchKernelGGL((k_step_fused<8, 3, 3, 3>), grid, dim3(512), 0, s, p); break;
+        case 422: hipLaunchKernelGGL((k_step_fused<8, 4, 2, 2>), grid, dim3(512), 0, s, p); break;
+        default: hipLaunchKernelGGL((k_step_fused<8, 4, 3, 2>), grid, dim3(512), 0, s, p); break;
     }
 }
 
@@ -343,18 +393,16 @@ void fused_dump_stamps(FusedPlan *p, hipStream_t s)
     fprintf(f, "# pos slot x0 y0 ox oy variant cyl | t0..t9 xcc hwid realtime variant\n");
     for (size_t i = 0; i < nt; ++i) {
         const TileDesc &t = p->hp.tiles[i];
-        fprintf(f, "%zu %d %d %d %d %d %d %d |", i, t.slot, t.x0, t.y0, t.ox, t.oy, t.variant, t.cyl_count);
-        for (int k = 0; k < 14; ++k) fprintf(f, " %llu", h[(size_t)t.slot * 16 + k]);
+        fprintf(f, "%zu %d %d %d %d %d %d %d |", i, t.slot, t.x0, t.y0, t.ox, t.oy, t.aux | (t.edge << 4), t.cyl_count);
+        for (int k = 0; k < 15; ++k) fprintf(f, " %llu", h[(size_t)t.slot * 16 + k]);
         fprintf(f, "\n");
     }
     fclose(f);
 }
 
-void fused_variant_counts(const FusedPlan *p, int out[3])
+void fused_variant_counts(const FusedPlan *p, int out[4])
 {
-    out[0] = p->hp.count[0];
-    out[1] = p->hp.count[1];
-    out[2] = p->hp.count[2];
+    for (int k = 0; k < 4; ++k) out[k] = p->hp.count[k];
 }
 
 }  // namespace wv
