@@ -35,6 +35,13 @@ N_GRID = 700
 STEPS_PER_ACTION = 100
 
 
+def baseline_metric() -> str:
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "Mcell-updates/s (700^2 grid, 100 integ steps) + achieved HBM GB/s vs peak"
+
+
 def cpu_baseline(n_steps: int):
     """The C oracle ("port" of the reference algorithm, 1 core like the reference's single-threaded Julia CPU path) timed
     on this host on a bounded sample of the same workload."""
@@ -146,7 +153,7 @@ def main():
                 traffic = None
         kname = "k_step_fused" if impl == "fused" else "k_stage"
         out = {
-            "metric": "Mcell-updates/s (700^2 grid, 100 integ steps)",
+            "metric": baseline_metric(),
             "value": round(value, 2),
             "unit": "Mcell-updates/s",
             "n_gpus": world,

@@ -1,0 +1,76 @@
+"""The N > 1 path on CPU: two `gloo` ranks (world_size 2) exercise the sharding, the design-space broadcast, a field
+broadcast and the trace gather of waves.jl_amd/dist.py -- the only communication the episode-parallel path has."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+import waves_jl_amd as w
+from waves_jl_amd import dist as wd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_episodes_partitions_contiguously():
+    for E, W in ((64, 8), (64, 1), (10, 4), (3, 8)):
+        got = [list(wd.shard_episodes(E, W, r)) for r in range(W)]
+        flat = [e for g in got for e in g]
+        assert flat == list(range(E))
+        assert max(len(g) for g in got) - min(len(g) for g in got) <= 1
+    assert list(wd.shard_episodes(64, 8, 3)) == list(range(24, 32))   # config 3: rank r takes episodes 8r..8r+7
+
+
+def test_pack_unpack_design_space_roundtrip():
+    ds = w.build_triple_ring_design_space()
+    back = wd.unpack_design_space(wd.pack_design_space(ds))
+    for a, b in ((ds.low, back.low), (ds.high, back.high)):
+        assert np.array_equal(a.stacked().pos, b.stacked().pos)
+        assert np.array_equal(a.stacked().r, b.stacked().r) and np.array_equal(a.stacked().c, b.stacked().c)
+    assert len(back.low.config) == 18 and len(back.low.core) == 1
+
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, {root!r})
+    import numpy as np
+    import waves_jl_amd as w
+    from waves_jl_amd import dist as wd
+    rank, local_rank, world = wd.init("gloo")
+    assert world == 2
+    ds = w.build_triple_ring_design_space() if rank == 0 else None
+    ds = wd.broadcast_design_space(ds, src=0)
+    ref = w.build_triple_ring_design_space()
+    assert np.array_equal(ds.high.stacked().r, ref.high.stacked().r)
+    assert np.array_equal(ds.low.stacked().pos, ref.low.stacked().pos)
+    field = np.arange(12, dtype=np.float32).reshape(3, 4) if rank == 0 else None
+    field = wd.broadcast_field(field, (3, 4), src=0)
+    assert np.array_equal(field, np.arange(12, dtype=np.float32).reshape(3, 4))
+    mine = list(wd.shard_episodes(6, world, rank))
+    sig = np.stack([np.full((5, 3), 10.0 * e + rank, np.float32) for e in mine])
+    allsig = wd.gather_signals(sig)
+    assert len(allsig) == 2 and allsig[0][0, 0, 0] == 0.0 and allsig[1][0, 0, 0] == 31.0
+    assert wd.max_over_ranks(1.0 + rank) == 2.0
+    wd.barrier()
+    wd.finalize()
+    print("rank", rank, "ok")
+""")
+
+
+def test_two_gloo_ranks():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER.format(root=ROOT)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o
