@@ -69,6 +69,44 @@ def cpu_baseline(n_steps: int):
                       "oracle/waves_oracle.c single thread"}
 
 
+def batched_envs(w, dim, ds, dev, impl, n_envs, pml_width, actions=6):
+    """BASELINE config 3 shape on one GPU: n_envs independent 700^2 environments, each on its own HIP stream, stepped
+    concurrently (step_begin on all, then step_end on all).  Reported next to the headline, never as `value`."""
+    import torch
+    envs, pols = [], []
+    for e in range(n_envs):
+        src = w.RandomPosGaussianSource(w.build_grid(dim), [[-10.0, -10.0]], [[-10.0, 10.0]], [0.3], [1.0], 1000.0,
+                                        rng=np.random.default_rng(500 + e))
+        env = w.WaveEnv(dim, design_space=ds, source=src, integration_steps=STEPS_PER_ACTION, actions=actions + 4,
+                        device=dev, impl=impl, rng=np.random.default_rng(600 + e), return_fields=False,
+                        pml_width=pml_width)
+        env.reset()
+        envs.append(env)
+        pols.append(w.RandomDesignPolicy(env.action_space(), np.random.default_rng(700 + e)))
+
+    def sweep():
+        for env, pol in zip(envs, pols):
+            env.step_begin(pol(env))
+        for env in envs:
+            env.step_end()
+
+    sweep()
+    sweep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(actions):
+        sweep()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = len(dim.x)
+    val = n_envs * actions * STEPS_PER_ACTION * n * n / dt / 1e6
+    for env in envs:
+        env.ctx.close()
+    return {"envs_per_gpu": n_envs, "value": round(val, 2), "unit": "Mcell-updates/s",
+            "whole_job_frac": round(B_ALG * val * 1e6 / (HBM_PEAK_GBS * 1e9), 4),
+            "note": "independent envs overlapped on separate HIP streams (BASELINE config 3 shape); not the headline"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,7 +114,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--impl", default="auto", choices=["auto", "staged", "fused"])
     ap.add_argument("--cpu-steps", type=int, default=40, help="integration steps of the cpu_baseline sample (0 = skip)")
-    ap.add_argument("--grid", type=int, default=N_GRID)
+    ap.add_argument("--grid", type=int, default=N_GRID, help="grid points per axis (700 = the metric's configuration)")
+    ap.add_argument("--pml-width", type=float, default=2.0)
+    ap.add_argument("--batch-envs", type=int, default=8,
+                    help="extra (untimed-for-`value`) measurement: this many independent envs stepped concurrently on the "
+                         "GPU, BASELINE config 3's 8-per-GPU shape (0 = skip)")
     args = ap.parse_args()
 
     import torch  # first: the HIP runtime both torch and libwaves_amd use is then torch's
@@ -100,7 +142,8 @@ def main():
                                     rng=np.random.default_rng(2 + 1000 * rank))
     total_actions = args.warmup + args.steps
     env = w.WaveEnv(dim, design_space=ds, source=src, integration_steps=STEPS_PER_ACTION, actions=total_actions + 8,
-                    device=dev, impl=args.impl, rng=np.random.default_rng(1000 * rank), return_fields=False)
+                    device=dev, impl=args.impl, rng=np.random.default_rng(1000 * rank), return_fields=False,
+                    pml_width=args.pml_width)
     policy = w.RandomDesignPolicy(env.action_space(), np.random.default_rng(1 + 1000 * rank))
     env.reset()
 
@@ -146,7 +189,7 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and ngrid == N_GRID:
             try:
                 traffic = json.load(open(tpath)).get(impl)
             except Exception:
@@ -167,7 +210,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"TwoDim(15.0f0, {ngrid}) + triple-ring design_space, RandomPosGaussianSource, "
                                    f"{STEPS_PER_ACTION} integration steps per env action, RandomDesignPolicy",
-                       "impl": impl, "envs_per_gpu": 1,
+                       "impl": impl, "envs_per_gpu": 1, "pml_width": args.pml_width,
                        "device_ms_per_step": round(dev_ms / args.steps, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kname,
@@ -176,6 +219,8 @@ def main():
                          "whole_job_frac": round(B_ALG * value * 1e6 / world / (HBM_PEAK_GBS * 1e9), 4)},
             "signal_checksum": float(np.sum(all_sig[0][-1])),
         }
+        if world == 1 and args.batch_envs > 1:
+            out["batched"] = batched_envs(w, dim, ds, dev, args.impl, args.batch_envs, args.pml_width)
         if world == 1 and args.cpu_steps > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
     wd.barrier()

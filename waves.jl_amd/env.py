@@ -76,6 +76,13 @@ class WaveEnv:
 
     def __call__(self, action):
         """(env::WaveEnv)(action)  src/env.jl:91-121."""
+        self.step_begin(action)
+        return self.step_end()
+
+    def step_begin(self, action):
+        """First half of env(action): enqueue the whole action on the env's HIP stream and return.  Several envs on one
+        GPU overlap this way (`for e in envs: e.step_begin(a)` then `for e in envs: e.step_end()`): while one env's
+        tiles are in their load phase another's are computing (BASELINE config 3: 8 episodes per GPU)."""
         tspan = self.build_tspan()
         ti = self.time()
         current_design = self.design
@@ -84,8 +91,14 @@ class WaveEnv:
         if self.integration_steps < 2 * FRAMESKIP:
             raise IndexError("BoundsError: sol[:, :, :, end-20:10:end] needs integration_steps >= 20 (src/env.jl:116)")
         self.ctx.set_design(*interp.abi_args())             # C = t -> speed(interp(t), grid, c0)
-        sig, u_tot, u_inc = self.ctx.integrate(tspan, capture_frames=True, want_signal=True,
-                                               want_fields=self.return_fields)
+        self.ctx.integrate_begin(tspan, capture_frames=True, want_signal=True, want_fields=self.return_fields)
+        self._pending = (tspan, interp, next_design)
+
+    def step_end(self):
+        """Second half of env(action): wait for the device and update the env's bookkeeping (src/env.jl:114-120)."""
+        tspan, interp, next_design = self._pending
+        self._pending = None
+        sig, u_tot, u_inc = self.ctx.integrate_end()
         self.signal = sig                                   # hcat(tot_energy, inc_energy, sc_energy)
         self.design = next_design
         self.time_step += self.integration_steps
