@@ -27,16 +27,19 @@ using namespace wv;
 
 static F2 g_lds_raw[lds_elems(8 * 6)];  // deliberately NOT cleared between tiles: stale contents must never matter
 
-template <int AUX, int NW, int RPT, int RYMAX>
+static int g_force_all = 0;  // 1: every tile runs the F_ALL instantiation (must give the same bits as the specialised ones)
+
+template <int AUX, int FL, int NW, int RPT, int RYMAX>
 static void run_tile(const FusedParams &p, const TileDesc &t, double esum[3])
 {
     constexpr int NT = NW * 64;
     const FusedLds lds = lds_view(g_lds_raw, NW * RPT, RYMAX);
     std::vector<FusedRegs<AUX, RPT>> regs(NT);
-    for (int tid = 0; tid < NT; ++tid) fused_load<AUX, NW, RPT>(p, t, tid, lds, regs[tid]);
-#define STAGE(S)                                                                                   \
-    for (int tid = 0; tid < NT; ++tid) fused_publish<AUX, NW, RPT, S>(p, t, tid, lds, regs[tid]);  \
-    for (int tid = 0; tid < NT; ++tid) fused_compute<AUX, NW, RPT, S>(p, t, tid, lds, regs[tid]);
+    std::vector<TileCtx> cx(NT);
+    for (int tid = 0; tid < NT; ++tid) fused_load<AUX, FL, NW, RPT>(p, t, tid, lds, cx[tid], regs[tid]);
+#define STAGE(S)                                                                                                \
+    for (int tid = 0; tid < NT; ++tid) fused_publish<AUX, FL, NW, RPT, S>(p, t, tid, lds, cx[tid], regs[tid]);  \
+    for (int tid = 0; tid < NT; ++tid) fused_compute<AUX, FL, NW, RPT, S>(p, t, tid, lds, cx[tid], regs[tid]);
     STAGE(1) STAGE(2) STAGE(3) STAGE(4)
 #undef STAGE
     for (int tid = 0; tid < NT; ++tid) {
@@ -53,11 +56,23 @@ static void run_step(const FusedParams &p, const HostPlan &pl, double esum[3])
     constexpr int RYMAX = NW * RMAX;
     static_assert(RYMAX <= 48, "g_lds_raw too small");
     for (const TileDesc &t : pl.tiles) {
-        switch (t.aux) {
-            case AUX_NONE: run_tile<AUX_NONE, NW, RF, RYMAX>(p, t, esum); break;
-            case AUX_PX: run_tile<AUX_PX, NW, RB, RYMAX>(p, t, esum); break;
-            case AUX_PY: run_tile<AUX_PY, NW, RB, RYMAX>(p, t, esum); break;
-            default: run_tile<AUX_ALL, NW, RP, RYMAX>(p, t, esum); break;
+        const int fl = g_force_all ? F_ALL : tile_flags(p, t);  // the dispatch of k_step_fused
+        constexpr int F_ES = F_EDGE | F_SRC, F_CS = F_CYL | F_SRC;
+        if (t.aux == AUX_NONE) {
+            if (fl == 0) run_tile<AUX_NONE, 0, NW, RF, RYMAX>(p, t, esum);
+            else if (fl == F_SRC) run_tile<AUX_NONE, F_SRC, NW, RF, RYMAX>(p, t, esum);
+            else if (!(fl & F_EDGE)) run_tile<AUX_NONE, F_CS, NW, RF, RYMAX>(p, t, esum);
+            else run_tile<AUX_NONE, F_ALL, NW, RF, RYMAX>(p, t, esum);   // only via force_all (never planned)
+        } else if (t.aux == AUX_PX) {
+            if (!(fl & F_CYL)) run_tile<AUX_PX, F_ES, NW, RB, RYMAX>(p, t, esum);
+            else run_tile<AUX_PX, F_ALL, NW, RB, RYMAX>(p, t, esum);
+        } else if (t.aux == AUX_PY) {
+            if (fl == 0) run_tile<AUX_PY, 0, NW, RB, RYMAX>(p, t, esum);
+            else if (!(fl & F_CYL)) run_tile<AUX_PY, F_ES, NW, RB, RYMAX>(p, t, esum);
+            else run_tile<AUX_PY, F_ALL, NW, RB, RYMAX>(p, t, esum);
+        } else {
+            if (!(fl & F_CYL)) run_tile<AUX_ALL, F_ES, NW, RP, RYMAX>(p, t, esum);
+            else run_tile<AUX_ALL, F_ALL, NW, RP, RYMAX>(p, t, esum);
         }
     }
 }
@@ -82,7 +97,7 @@ struct Case {
     int aux;         // 1: random non-zero auxiliary fields everywhere (forces AUX_ALL tiles); 0: only where they may be
                      // non-zero (Psi_x where sigma_x != 0, ...) -> reduced field sets
     int src_mode = 1;  // 1: per-tile source flags computed; 0: src_flags = nullptr (assume non-zero everywhere)
-    int force_all;   // 1: natural launch order instead of the XCD-aware one
+    int force_all;   // 1: natural launch order instead of the XCD-aware one AND every tile through the F_ALL body
 };
 
 static int run_case(const Case &cs)
@@ -157,6 +172,7 @@ static int run_case(const Case &cs)
         }
     }
     HostPlan pl;
+    g_force_all = cs.force_all;
     if (!plan_build_tiles(pl, n, n, cs.NW * cs.RF, cs.NW * cs.RB, cs.NW * cs.RP, x.data(), x.data(), sx.data(), sx.data(),
                           cs.aux == 0, cs.force_all == 0)) {
         printf("%-28s plan_build_tiles failed\n", cs.name);
@@ -186,8 +202,7 @@ static int run_case(const Case &cs)
         p.c0 = c0; p.c0sq = c0 * c0;
         p.u = cur; p.out = nxt; p.G = cs.source ? G.data() : nullptr;
         p.src_flags = (cs.source && cs.src_mode) ? flags.data() : nullptr;
-        p.sfac[0] = sfac[3 * s]; p.sfac[1] = sfac[3 * s + 1]; p.sfac[2] = sfac[3 * s + 2];
-        p.cyl = table.data() + (size_t)(3 * s) * M; p.M = M;
+        p.step = s; p.sfac_tab = sfac.data(); p.cyl_tab = table.data(); p.M = M; p.tile_offset = 0;
         p.dt = dt; p.hdt = hdt;
         p.tiles = pl.tiles.data(); p.cyl_idx = idx.data();
         p.epart = nullptr; p.traj_tot = nullptr; p.traj_inc = nullptr; p.stamps = nullptr;

@@ -313,3 +313,27 @@ def test_error_behaviour():
     ctx.close()
     with pytest.raises(AssertionError):                  # src/env.jl:52
         w.WaveEnv(w.TwoDim(15.0, 64), design_space=w.build_triple_ring_design_space(), resolution=(128, 128))
+
+
+def test_recycled_device_memory_does_not_leak_into_results():
+    """contexts created after others were destroyed get recycled (non-zero) device memory: the reduced field sets of the
+    fused kernel must not depend on what a buffer held before (regression: scratch states are zeroed at wv_create)"""
+    rng = np.random.default_rng(5)
+    for rep in range(3):
+        dim, ctx = make_ctx(96, "fused", size=5.0, pml=(1.0, 0.0))
+        junk = random_state(rng, 96, 96, scale=1e3)
+        ctx.set_frames(np.stack([junk] * 3, axis=3))
+        ctx.integrate(wo.build_tspan(0.0, 1e-5, 25), capture_frames=True, want_signal=False)   # dirties every buffer
+        ctx.close()
+    dim, ctx = make_ctx(96, "fused", size=5.0, pml=(1.0, 0.0))
+    ic = wo.build_normal(wo.build_grid(dim), np.array([[0.0, 0.0]]), np.array([0.3]), np.array([1.0]))
+    u0 = np.zeros((96, 96, 12), f32, order="F")
+    u0[:, :, 0] = ic
+    u0[:, :, 6] = ic
+    ctx.set_source_shape(None, 0.0)
+    ctx.set_state(u0)
+    ts = wo.build_tspan(0.0, 1e-5, 30)
+    ctx.integrate(ts, want_signal=False)
+    st, _, _ = oracle_integrate(dim, wo.to_abi(u0), ts, pml=(1.0, 0.0))
+    assert np.array_equal(wo.to_abi(ctx.get_state()), st)
+    ctx.close()

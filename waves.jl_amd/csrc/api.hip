@@ -51,6 +51,9 @@ struct wv_ctx {
     size_t traj_cap = 0;
     float *d_small = nullptr;  // gaussian parameters
     size_t small_cap = 0;
+    float *d_sfac = nullptr;   // per-step source time factors [nsteps][3]
+    size_t sfac_cap = 0;
+    std::vector<FusedStep> fsteps;
     float *d_elast = nullptr;  // per-block energy partials of the state the last integrate ended on
     size_t elast_cap = 0;
     int elast_generation = -1;
@@ -208,7 +211,7 @@ int wv_destroy(wv_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     float *bufs[] = {c->d_x, c->d_y, c->d_sx, c->d_sy, c->d_frames, c->d_scratch[0], c->d_scratch[1], c->d_yA, c->d_yB,
                      c->d_acc, c->d_G, c->d_plane[0], c->d_plane[1], c->d_epart, c->d_signal, c->d_traj, c->d_small,
-                     c->d_elast};
+                     c->d_elast, c->d_sfac};
     for (float *b : bufs)
         if (b) (void)hipFree(b);
     if (c->d_cyl) (void)hipFree(c->d_cyl);
@@ -293,6 +296,9 @@ int wv_create(const wv_config *cfg, const float *x, const float *y, wv_ctx **out
     CK(hipMemcpy(c->d_sx, c->sx.data(), c->nx * sizeof(float), hipMemcpyHostToDevice));
     CK(hipMemcpy(c->d_sy, c->sy.data(), c->ny * sizeof(float), hipMemcpyHostToDevice));
     CK(hipMemset(c->d_frames, 0, 3 * c->N * sizeof(float)));
+    // the reduced field sets of the fused kernel rely on unwritten planes of every output buffer holding zeros
+    CK(hipMemset(c->d_scratch[0], 0, c->N * sizeof(float)));
+    CK(hipMemset(c->d_scratch[1], 0, c->N * sizeof(float)));
     CK(hipMemset(c->d_G, 0, c->P * sizeof(float)));
 #undef CK
 
@@ -573,6 +579,9 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     if (rc) return rc;
     if (M > 0)
         HIPCHK(c, hipMemcpyAsync(c->d_cyl, c->h_cyl.data(), c->h_cyl.size() * sizeof(Cyl), hipMemcpyHostToDevice, c->stream));
+    rc = ensure(c, &c->d_sfac, &c->sfac_cap, c->h_sfac.size());
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_sfac, c->h_sfac.data(), c->h_sfac.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
 
     if (impl == WV_IMPL_FUSED) {
         rc = fused_prepare(c->fused, c->d_frames, c->d_scratch[0], c->d_scratch[1], capture != 0,
@@ -623,6 +632,8 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     if (capture && nsteps == 2 * WV_FRAMESKIP)
         HIPCHK(c, hipMemcpyAsync(frame(c, 0), cur, c->N * sizeof(float), hipMemcpyDeviceToDevice, st));
 
+    const FusedCall fcall{c->has_source ? c->d_G : nullptr, c->has_source ? c->d_sfac : nullptr, dt};
+    c->fsteps.clear();
     for (int s = 1; s <= nsteps; ++s) {
         float *out;
         if (capture && s == nsteps - 2 * WV_FRAMESKIP) out = frame(c, 0);
@@ -664,17 +675,18 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
             FusedStep fs{};
             fs.u = cur;
             fs.out = out;
-            fs.G = G;
-            fs.sfac[0] = sf[0]; fs.sfac[1] = sf[1]; fs.sfac[2] = sf[2];
-            fs.table_row = 3 * (s - 1);
-            fs.dt = dt;
             fs.epart = ep;
             fs.traj_tot = tts;
             fs.traj_inc = tis;
-            fused_launch(c->fused, fs, st);
+            if (c->profiling) fused_launch(c->fused, fcall, s - 1, fs, st);  // eager, bracketed by events
+            else c->fsteps.push_back(fs);                                     // launched together below
         }
         if (c->profiling) HIPCHK(c, hipEventRecord(c->kev[2 * (s - 1) + 1], st));
         cur = out;
+    }
+    if (impl == WV_IMPL_FUSED && !c->profiling) {
+        if (fused_run(c->fused, fcall, c->fsteps.data(), (int)c->fsteps.size(), st) != 0)
+            return fail(c, WV_ERR_HIP, std::string("fused_run failed: ") + hipGetErrorString(hipGetLastError()));
     }
     HIPCHK(c, hipGetLastError());
     if (want_signal) {

@@ -7,16 +7,20 @@ namespace wv {
 
 struct FusedPlan;
 
+// What differs between the steps of one wv_integrate call (everything else is per-call).
 struct FusedStep {
     const float *u;     // state at the start of the step (12 planes)
     float *out;         // state at the end of the step (12 planes, != u)
-    const float *G;     // source shape or nullptr
-    float sfac[3];      // source time factor at t, t + dt/2, t + dt
-    int table_row;      // row of the cylinder table holding stage time t (rows +1, +2: t + dt/2, t + dt)
-    float dt;
-    float *epart;       // per-block energy partials [fused_energy_blocks][3] or nullptr
+    float *epart;       // per-tile energy partials [fused_energy_blocks][3] or nullptr
     float *traj_tot;    // optional copies of the new U_tot / U_inc planes
     float *traj_inc;
+};
+
+// Per-call arguments shared by all steps.
+struct FusedCall {
+    const float *G;         // device source shape or nullptr (NoSource)
+    const float *d_sfac;    // device [nsteps][3] source time factors (nullptr when G is)
+    float dt;
 };
 
 FusedPlan *fused_create(const Grid &g, const float *x_host, const float *y_host, const float *sx_host,
@@ -37,7 +41,12 @@ void fused_dump_stamps(FusedPlan *p, hipStream_t s);  // diagnostic, no-op unles
 int fused_prepare(FusedPlan *p, float *frames, float *scratch0, float *scratch1, bool capture, const float *G,
                   const Cyl *d_table, const Cyl *h_table, int M, int rows, hipStream_t s);
 void fused_source_changed(FusedPlan *p);  // the source shape was replaced
-void fused_launch(FusedPlan *p, const FusedStep &st, hipStream_t s);
+// one step, eagerly, as a single launch over all tiles (profiling mode brackets these with events)
+void fused_launch(FusedPlan *p, const FusedCall &call, int step, const FusedStep &st, hipStream_t s);
+// all steps of a call: a cached hipGraph of (step, band) kernel nodes with neighbour-band dependencies when enabled
+// (consecutive steps then overlap: one band's load / start-up / write-back hides under another band's compute), else
+// eager launches.  Returns 0 on success.
+int fused_run(FusedPlan *p, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s);
 void fused_variant_counts(const FusedPlan *p, int out[4]);  // tiles per field set: NONE, PX, PY, ALL
 
 }  // namespace wv

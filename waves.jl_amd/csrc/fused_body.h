@@ -63,11 +63,15 @@ struct FusedParams {
     float *out;       // state at the end of the step
     const float *G;   // source shape or nullptr (NoSource)
     const unsigned char *src_flags;  // per tile slot: shape != 0 somewhere in the region (nullptr: assume yes)
-    float sfac[3];    // sin(2f0*pi*t*freq) at t, t + dt/2, t + dt
-    const Cyl *cyl;   // 3 rows of M cylinders: stage times t, t + dt/2, t + dt
+    // Per-step scalars live in device tables indexed by `step`, so that the kernel arguments of a given step are the
+    // same for every wv_integrate call of the same shape (a captured hipGraph can then be replayed unchanged).
+    int step;               // integration step of this call, 0-based
+    const float *sfac_tab;  // [nsteps][3]  sin(2f0*pi*t*freq) at t, t + dt/2, t + dt
+    const Cyl *cyl_tab;     // [nsteps][3][M] cylinders at the three stage times
     int M;
     float dt, hdt;
     const TileDesc *tiles;
+    int tile_offset;  // first tile of this launch (a launch covers one band of tiles)
     const int *cyl_idx;
     float *epart;     // [ntiles][3] or nullptr
     float *traj_tot;  // optional copies of the new U_tot / U_inc planes
@@ -116,53 +120,83 @@ struct FusedRegs {
 
 WV_HD int stage_q(int S) { return S == 1 ? 0 : (S == 4 ? 2 : 1); }  // which of the three stage times a stage uses
 
-// speed(design, grid, c0) at one cell from the tile's culled cylinder list (culled cylinders would add an exact 0).
-// src/designs.jl:99-116.  No FMA may be formed here (-ffp-contract=off).  The list is read from the LDS copy made by
-// fused_load (one broadcast ds_read_b128 per cylinder) or, for tiles with more than FT_MAXCYL cylinders, from global.
-WV_HD bool tile_cyl_in_lds(const TileDesc &t) { return t.cyl_count > 0 && t.cyl_count <= FT_MAXCYL; }
+// Compile-time feature flags of a tile body (template parameter FL).  A flag that is compiled in but not needed by the
+// tile at hand is harmless (every use is still guarded by the tile's run-time data); a flag that is NOT compiled in
+// removes the code -- and its scalar branches -- altogether.  The kernel picks the smallest instantiated superset.
+enum : int { F_EDGE = 1, F_CYL = 2, F_SRC = 4, F_ALL = 7 };
 
-WV_HD float tile_speed(const FusedParams &p, const TileDesc &t, const FusedLds &lds, int q, float x, float y)
-{
-    const bool staged = tile_cyl_in_lds(t);
-    const Cyl *row = p.cyl + (size_t)q * p.M;
-    const int n = t.cyl_count < 0 ? p.M : t.cyl_count;
-    int count = 0;
-    float cd = 0.0f;
-    for (int k = 0; k < n; ++k) {
-        const Cyl c = staged ? lds.cyl[q * t.cyl_count + k] : row[t.cyl_count < 0 ? k : p.cyl_idx[t.cyl_begin + k]];
-        const float ddx = x - c.px;
-        const float ddy = y - c.py;
-        const float d2 = ddx * ddx + ddy * ddy;
-        const bool in = d2 < c.r2;
-        count += in ? 1 : 0;
-        cd = cd + (in ? c.c : 0.0f);
-    }
-    const float C0 = count == 0 ? p.c0 : 0.0f;
-    return C0 + cd;
-}
+// Block-uniform values fetched once per tile (they live in SGPRs): re-reading them from memory in every phase costs a
+// dependent load per phase on a path whose length is what bounds the kernel.
+struct TileCtx {
+    float sf[3];   // sin(2f0*pi*t*freq) at the three stage times of this step (0 without a source)
+    bool has_src;  // the source shape is non-zero somewhere in this tile's region
+    bool has_cyl;  // at least one cylinder can reach this tile's region
+    bool cyl_lds;  // ... and the culled list is staged in LDS
+};
 
 WV_HD bool tile_has_src(const FusedParams &p, const TileDesc &t)
 {
     return p.G != nullptr && (p.src_flags == nullptr || p.src_flags[t.slot] != 0);
 }
 
+WV_HD int tile_flags(const FusedParams &p, const TileDesc &t)
+{
+    return (t.edge ? F_EDGE : 0) | ((p.M > 0 && t.cyl_count != 0) ? F_CYL : 0) | (tile_has_src(p, t) ? F_SRC : 0);
+}
+
+// speed(design, grid, c0) at one cell from the tile's culled cylinder list (culled cylinders would add an exact 0).
+// src/designs.jl:99-116.  No FMA may be formed here (-ffp-contract=off).  The list is read from the LDS copy made by
+// fused_load (one broadcast ds_read_b128 per cylinder) or, for tiles with more than FT_MAXCYL cylinders, from global.
+WV_HD void speed_accum(const Cyl c, float x, float y, int &count, float &cd)
+{
+    const float ddx = x - c.px;
+    const float ddy = y - c.py;
+    const float d2 = ddx * ddx + ddy * ddy;
+    const bool in = d2 < c.r2;
+    count += in ? 1 : 0;
+    cd = cd + (in ? c.c : 0.0f);
+}
+
+WV_HD float tile_speed(const FusedParams &p, const TileDesc &t, const TileCtx &cx, const FusedLds &lds, int q, float x,
+                       float y)
+{
+    int count = 0;
+    float cd = 0.0f;
+    if (cx.cyl_lds) {
+        const Cyl *row = lds.cyl + q * t.cyl_count;
+        for (int k = 0; k < t.cyl_count; ++k) speed_accum(row[k], x, y, count, cd);
+    } else {
+        const Cyl *row = p.cyl_tab + (size_t)(3 * p.step + q) * p.M;
+        const int n = t.cyl_count < 0 ? p.M : t.cyl_count;
+        for (int k = 0; k < n; ++k) speed_accum(row[t.cyl_count < 0 ? k : p.cyl_idx[t.cyl_begin + k]], x, y, count, cd);
+    }
+    const float C0 = count == 0 ? p.c0 : 0.0f;
+    return C0 + cd;
+}
+
 // ---- phase 0: global -> registers ---------------------------------------------------------------------------
-template <int AUX, int NW, int RPT>
-WV_HD void fused_load(const FusedParams &p, const TileDesc &t, int tid, const FusedLds &lds, FusedRegs<AUX, RPT> &r)
+template <int AUX, int FL, int NW, int RPT>
+WV_HD void fused_load(const FusedParams &p, const TileDesc &t, int tid, const FusedLds &lds, TileCtx &cx,
+                      FusedRegs<AUX, RPT> &r)
 {
     constexpr int NS = aux_ns(AUX);
     const int lane = tid & 63, w = tid >> 6;
     const int gx = t.x0 - FT_H + lane;
     const bool inx = gx >= 0 && gx < p.nx;
     const int cgx = gx < 0 ? 0 : (gx >= p.nx ? p.nx - 1 : gx);
-    const bool has_src = tile_has_src(p, t);
+    cx.has_src = (FL & F_SRC) ? tile_has_src(p, t) : false;
+    cx.has_cyl = (FL & F_CYL) ? (p.M > 0 && t.cyl_count != 0) : false;
+    cx.cyl_lds = cx.has_cyl && t.cyl_count > 0 && t.cyl_count <= FT_MAXCYL;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) cx.sf[q] = (cx.has_src && p.sfac_tab) ? p.sfac_tab[3 * p.step + q] : 0.0f;
     r.sx = (AUX == AUX_PX || AUX == AUX_ALL) ? p.sx[cgx] : 0.0f;
     r.xs = 0.0f;
-    if (p.M > 0 && t.cyl_count != 0) {  // block-uniform
+    if ((FL & F_CYL) && cx.has_cyl) {  // block-uniform
         r.xs = p.x[cgx];
         // stage the culled cylinders of the three stage times in LDS; first read after the first barrier of stage 1
-        if (tile_cyl_in_lds(t) && tid < 3 * t.cyl_count)
-            lds.cyl[tid] = p.cyl[(size_t)(tid / t.cyl_count) * p.M + p.cyl_idx[t.cyl_begin + tid % t.cyl_count]];
+        if (cx.cyl_lds && tid < 3 * t.cyl_count)
+            lds.cyl[tid] = p.cyl_tab[(size_t)(3 * p.step + tid / t.cyl_count) * p.M +
+                                     p.cyl_idx[t.cyl_begin + tid % t.cyl_count]];
     }
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
@@ -171,7 +205,7 @@ WV_HD void fused_load(const FusedParams &p, const TileDesc &t, int tid, const Fu
         const bool in = inx && gy >= 0 && gy < p.ny && ly < t.oy + 2 * FT_H;
         const int cgy = gy < 0 ? 0 : (gy >= p.ny ? p.ny - 1 : gy);
         const unsigned id = (unsigned)cgy * (unsigned)p.nx + (unsigned)cgx;
-        r.g[rr] = (has_src && in) ? p.G[id] : 0.0f;
+        r.g[rr] = ((FL & F_SRC) && cx.has_src && in) ? p.G[id] : 0.0f;
         r.b[rr] = p.c0sq;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -184,15 +218,14 @@ WV_HD void fused_load(const FusedParams &p, const TileDesc &t, int tid, const Fu
 }
 
 // ---- phase "publish": the stage input's stencil fields -> LDS ------------------------------------------------
-template <int AUX, int NW, int RPT, int S>
-WV_HD void fused_publish(const FusedParams &p, const TileDesc &t, int tid, const FusedLds &lds,
+template <int AUX, int FL, int NW, int RPT, int S>
+WV_HD void fused_publish(const FusedParams &p, const TileDesc &t, int tid, const FusedLds &lds, const TileCtx &cx,
                          const FusedRegs<AUX, RPT> &r)
 {
     const int lane = tid & 63, w = tid >> 6;
     const int rows = t.oy + 2 * FT_H;
-    const float sf = p.sfac[stage_q(S)];
+    const float sf = cx.sf[stage_q(S)];
     const float cp = p.ops.cp;
-    const bool has_src = tile_has_src(p, t);
     const int gx = t.x0 - FT_H + lane;
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
@@ -200,7 +233,7 @@ WV_HD void fused_publish(const FusedParams &p, const TileDesc &t, int tid, const
         if (ly < S - 1 || ly >= rows - (S - 1)) continue;  // y_S is only needed on the region shrunk by S-1
         const float(&yin)[2][aux_ns(AUX)] = S == 1 ? r.u[rr] : r.y[rr];
         float wt = yin[0][0], wi = yin[1][0];
-        if (has_src) {
+        if (FL & F_SRC) {  // tiles whose region misses the source's support carry g == 0: U + (+-0) == U exactly
             const float f = r.g[rr] * sf;  // shape .* sin(...)      src/sources.jl:67-69
             wt = wt + f;                   // U .+ f                 src/dynamics.jl:166-167
             wi = wi + f;
@@ -209,7 +242,7 @@ WV_HD void fused_publish(const FusedParams &p, const TileDesc &t, int tid, const
         lds.W[i] = F2{cp * wt, cp * wi};
         lds.Vx[i] = F2{cp * yin[0][1], cp * yin[1][1]};
         lds.Vy[i] = F2{cp * yin[0][2], cp * yin[1][2]};
-        if (t.edge) {  // block-uniform: raw copies of the three cells next to a domain boundary
+        if ((FL & F_EDGE) && t.edge) {  // block-uniform: raw copies of the three cells next to a domain boundary
             const int gy = t.y0 - FT_H + ly;
             if ((t.edge & EDGE_L) && gx >= 0 && gx < 3) {
                 lds.XL[(ly * 3 + gx) * 2 + 0] = F2{wt, wi};
@@ -238,8 +271,8 @@ WV_HD F2 one_sided(float c0, float c1, float c2, F2 v0, F2 v1, F2 v2)
 }
 
 // ---- phase "compute": k_S from the LDS image, then the RK update of the registers ----------------------------
-template <int AUX, int NW, int RPT, int S>
-WV_HD void fused_compute(const FusedParams &p, const TileDesc &t, int tid, const FusedLds &lds,
+template <int AUX, int FL, int NW, int RPT, int S>
+WV_HD void fused_compute(const FusedParams &p, const TileDesc &t, int tid, const FusedLds &lds, const TileCtx &cx,
                          FusedRegs<AUX, RPT> &r)
 {
     constexpr int NS = aux_ns(AUX);
@@ -248,14 +281,13 @@ WV_HD void fused_compute(const FusedParams &p, const TileDesc &t, int tid, const
     const int lane = tid & 63, w = tid >> 6;
     const int rows = t.oy + 2 * FT_H;
     const int gx = t.x0 - FT_H + lane;
-    const bool has_cyl = p.M > 0 && t.cyl_count != 0;
     const Ops &o = p.ops;
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
         const int ly = w + NW * rr;
         if (ly < S || ly >= rows - S) continue;  // k_S is only needed on the region shrunk by S
         const int gy = t.y0 - FT_H + ly;
-        if (gy < 0 || gy >= p.ny) continue;
+        if ((FL & F_EDGE) && (gy < 0 || gy >= p.ny)) continue;
         const int i = lds_at(lane, ly);
         const F2 Wl = lds.W[i - 1], Wr = lds.W[i + 1], Wd = lds.W[i - FT_LX], Wu = lds.W[i + FT_LX];
         const F2 Xl = lds.Vx[i - 1], Xr = lds.Vx[i + 1], Yd = lds.Vy[i - FT_LX], Yu = lds.Vy[i + FT_LX];
@@ -264,7 +296,7 @@ WV_HD void fused_compute(const FusedParams &p, const TileDesc &t, int tid, const
         F2 Vxx = F2{Xr.x - Xl.x, Xr.y - Xl.y};
         F2 Vyy = F2{Yu.x - Yd.x, Yu.y - Yd.y};
         bool border = false;
-        if (t.edge) {  // block-uniform
+        if ((FL & F_EDGE) && t.edge) {  // block-uniform
             if ((t.edge & EDGE_L) && gx == 0) {
                 const F2 *v = lds.XL + ly * 6;
                 Ux = one_sided(o.f0, o.f1, o.f2, v[0], v[2], v[4]);
@@ -287,9 +319,9 @@ WV_HD void fused_compute(const FusedParams &p, const TileDesc &t, int tid, const
             }
             border = gx <= 0 || gy == 0 || gx >= p.nx - 1 || gy == p.ny - 1;
         }
-        if (S != 3 && has_cyl) {  // stage 3 shares t + dt/2 with stage 2
-            const float c = tile_speed(p, t, lds, stage_q(S), r.xs, p.y[gy]);  // C(t)   src/env.jl:99
-            r.b[rr] = c * c;                                                  // c .^ 2 src/dynamics.jl:159
+        if ((FL & F_CYL) && S != 3 && cx.has_cyl) {  // stage 3 shares t + dt/2 with stage 2
+            const float c = tile_speed(p, t, cx, lds, stage_q(S), r.xs, p.y[gy]);  // C(t)   src/env.jl:99
+            r.b[rr] = c * c;                                                       // c .^ 2 src/dynamics.jl:159
         }
         const float(&yin)[2][NS] = S == 1 ? r.u[rr] : r.y[rr];
         const float sx = r.sx;
@@ -297,7 +329,7 @@ WV_HD void fused_compute(const FusedParams &p, const TileDesc &t, int tid, const
         float k[2][NS];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const float b = s == 0 ? r.b[rr] : p.c0sq;
+            const float b = (s == 0 && (FL & F_CYL)) ? r.b[rr] : p.c0sq;
             const float ux = s == 0 ? Ux.x : Ux.y, uy = s == 0 ? Uy.x : Uy.y;
             const float vxx = s == 0 ? Vxx.x : Vxx.y, vyy = s == 0 ? Vyy.x : Vyy.y;
             const float U = yin[s][0];
@@ -306,7 +338,7 @@ WV_HD void fused_compute(const FusedParams &p, const TileDesc &t, int tid, const
             if (AUX == AUX_PX) dU = (dU + yin[s][3]) - sx * U;
             if (AUX == AUX_PY) dU = (dU + yin[s][3]) - sy * U;
             if (AUX == AUX_ALL) dU = (((dU + yin[s][3]) + yin[s][4]) - (sx + sy) * U) - yin[s][5];
-            if (border) dU = 0.0f * dU;  // bc .* dU   src/dynamics.jl:176, src/dims.jl:117-124
+            if ((FL & F_EDGE) && border) dU = 0.0f * dU;  // bc .* dU   src/dynamics.jl:176, src/dims.jl:117-124
             k[s][0] = dU;
             k[s][1] = HAS_SX ? ux - sx * yin[s][1] : ux;
             k[s][2] = HAS_SY ? uy - sy * yin[s][2] : uy;

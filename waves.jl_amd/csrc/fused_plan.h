@@ -13,7 +13,9 @@ namespace wv {
 struct HostPlan {
     int nx = 0, ny = 0;
     int RYF = 0, RYB = 0, RYP = 0;  // region rows of AUX_NONE tiles / AUX_PX+AUX_PY tiles / AUX_ALL tiles
-    std::vector<TileDesc> tiles;    // launch order (see plan_order)
+    std::vector<TileDesc> tiles;    // launch order: band-major, inside a band see plan_order
+    std::vector<int> band_begin;    // band b = tiles[band_begin[b] .. band_begin[b+1]); bands are contiguous ranges of
+                                    // x-strips, so a band's tiles only read halo cells of the two adjacent bands
     int count[4] = {0, 0, 0, 0};    // tiles per field set
     bool monotonic = true;          // x[] and y[] strictly increasing (needed for bounding-box culling)
 };
@@ -64,6 +66,28 @@ inline std::vector<PlanRun> plan_runs(const std::vector<char> &zero)
         while (e < n && zero[e] == zero[j]) ++e;
         runs.push_back(PlanRun{j, e - j, zero[j] != 0});
         j = e;
+    }
+    // A sigma == 0 run that reaches a domain boundary (no PML there, e.g. pml_scale = 0) is cut so that the pieces
+    // holding boundary cells form their own (non-zero class) run: AUX_NONE tiles then never need the boundary code.
+    const int carve = 2 * FT_H;
+    if (!runs.empty() && runs.front().zero) {
+        PlanRun &f = runs.front();
+        if (f.len >= 2 * carve + 3) {
+            runs.insert(runs.begin(), PlanRun{f.start, carve, false});
+            runs[1].start += carve;
+            runs[1].len -= carve;
+        } else {
+            f.zero = false;
+        }
+    }
+    if (!runs.empty() && runs.back().zero) {
+        PlanRun &b = runs.back();
+        if (b.len >= carve + 3) {
+            b.len -= carve;
+            runs.push_back(PlanRun{b.start + b.len, carve, false});
+        } else {
+            b.zero = false;
+        }
     }
     while (runs.size() > 1 && runs.front().len < 3) {
         runs[1].start = runs[0].start;
@@ -131,7 +155,7 @@ inline void plan_order(std::vector<TileDesc> &natural, std::vector<TileDesc> &ou
 // so tiles may carry reduced field sets -- and be taller, since a thread then carries less state per cell.  Otherwise
 // every tile is AUX_ALL.
 inline bool plan_build_tiles(HostPlan &pl, int nx, int ny, int RYF, int RYB, int RYP, const float *x, const float *y,
-                             const float *sx, const float *sy, bool reduced, bool xcd_aware)
+                             const float *sx, const float *sy, bool reduced, bool xcd_aware, int nbands = 1)
 {
     pl.nx = nx;
     pl.ny = ny;
@@ -154,10 +178,13 @@ inline bool plan_build_tiles(HostPlan &pl, int nx, int ny, int RYF, int RYB, int
     const std::vector<char> zx = plan_axis_zero(nx, sx), zy = plan_axis_zero(ny, sy);
     const std::vector<PlanRun> runs = plan_runs(zy);
     std::vector<TileDesc> all;
+    std::vector<size_t> strip_begin;
     int slot = 0;
     for (size_t a = 0; a < xs.size(); ++a) {
+        strip_begin.push_back(all.size());
         bool x_zero = reduced;
         for (int i = xs[a]; i < xs[a] + xl[a]; ++i) x_zero = x_zero && zx[i];
+        if (xs[a] - FT_H <= 0 || xs[a] + xl[a] + FT_H - 1 >= nx - 1) x_zero = false;  // boundary strips: never AUX_NONE/PY
         for (const PlanRun &run : runs) {
             const bool y_zero = reduced && run.zero;
             const int aux = x_zero ? (y_zero ? AUX_NONE : AUX_PY) : (y_zero ? AUX_PX : AUX_ALL);
@@ -182,6 +209,7 @@ inline bool plan_build_tiles(HostPlan &pl, int nx, int ny, int RYF, int RYB, int
                 if ((aux == AUX_NONE || aux == AUX_PY) && !sx_zero) return false;
                 if ((aux == AUX_NONE || aux == AUX_PX) && !sy_zero) return false;
                 if (aux != AUX_ALL && !reduced) return false;
+                if (aux == AUX_NONE && t.edge) return false;  // cannot happen: see plan_runs and the strip test above
                 if (t.oy > OY[aux] || t.ox > FT_X - 2 * FT_H) return false;
                 if ((t.x0 == 0 || t.x0 + t.ox == nx) && t.ox < 3) return false;  // boundary stencil reaches 2 inward
                 if ((t.y0 == 0 || t.y0 + t.oy == ny) && t.oy < 3) return false;
@@ -190,8 +218,32 @@ inline bool plan_build_tiles(HostPlan &pl, int nx, int ny, int RYF, int RYB, int
             }
         }
     }
-    plan_order(all, pl.tiles, xcd_aware);
-    return pl.tiles.size() == all.size();
+    strip_begin.push_back(all.size());
+    // bands: contiguous strip ranges of (nearly) equal cost
+    const int nstrips = (int)xs.size();
+    const int B = std::max(1, std::min(nbands, nstrips));
+    double total = 0.0;
+    for (const TileDesc &t : all) total += plan_tile_cost(t);
+    pl.tiles.clear();
+    pl.band_begin.assign(1, 0);
+    int a = 0;
+    double acc = 0.0;
+    for (int b = 0; b < B; ++b) {
+        std::vector<TileDesc> band, ordered;
+        const double target = total * (b + 1) / B;
+        while (a < nstrips && (band.empty() || nstrips - a > B - 1 - b)) {
+            double c = 0.0;
+            for (size_t k = strip_begin[a]; k < strip_begin[a + 1]; ++k) c += plan_tile_cost(all[k]);
+            if (!band.empty() && b < B - 1 && acc + 0.5 * c > target) break;
+            for (size_t k = strip_begin[a]; k < strip_begin[a + 1]; ++k) band.push_back(all[k]);
+            acc += c;
+            ++a;
+        }
+        plan_order(band, ordered, xcd_aware);
+        pl.tiles.insert(pl.tiles.end(), ordered.begin(), ordered.end());
+        pl.band_begin.push_back((int)pl.tiles.size());
+    }
+    return pl.tiles.size() == all.size() && a == nstrips;
 }
 
 // Per-tile list of the cylinders whose disc can reach the tile's region at ANY of the `rows` stage times of this

@@ -17,12 +17,13 @@ namespace wv {
 
 namespace {
 
-template <int AUX, int NW, int RPT, int RYMAX>
+template <int AUX, int FL, int NW, int RPT, int RYMAX>
 __device__ __forceinline__ void run_tile(const FusedParams &p, const TileDesc &t, F2 *raw, float e[3])
 {
     const int tid = threadIdx.x;
     const FusedLds lds = lds_view(raw, NW * RPT, RYMAX);
     FusedRegs<AUX, RPT> r;
+    TileCtx cx;
     // diagnostic stamps (p.stamps == nullptr in every normal run: one block-uniform branch per phase)
     unsigned long long *st = p.stamps ? p.stamps + (size_t)t.slot * 16 : nullptr;
 #define WV_STAMP(k)                                                     \
@@ -32,12 +33,12 @@ __device__ __forceinline__ void run_tile(const FusedParams &p, const TileDesc &t
     }
     WV_STAMP(0)
     if (st && tid == 0) st[14] = __builtin_amdgcn_s_memrealtime();
-    fused_load<AUX, NW, RPT>(p, t, tid, lds, r);
+    fused_load<AUX, FL, NW, RPT>(p, t, tid, lds, cx, r);
 #define WV_STAGE(S)                                          \
-    fused_publish<AUX, NW, RPT, S>(p, t, tid, lds, r);      \
+    fused_publish<AUX, FL, NW, RPT, S>(p, t, tid, lds, cx, r); \
     __syncthreads();                                         \
     WV_STAMP(2 * S - 1)                                      \
-    fused_compute<AUX, NW, RPT, S>(p, t, tid, lds, r);      \
+    fused_compute<AUX, FL, NW, RPT, S>(p, t, tid, lds, cx, r); \
     if (S < 4) __syncthreads();                              \
     WV_STAMP(2 * S)
     WV_STAGE(1)
@@ -65,16 +66,27 @@ __global__ __launch_bounds__(NW * 64, 4) void k_step_fused(FusedParams p)  // 4 
     constexpr int RYMAX = NW * RMAX;
     __shared__ F2 raw[lds_elems(RYMAX)];
     __shared__ float red[3][NW];
-    const TileDesc t = p.tiles[blockIdx.x];
+    const TileDesc t = p.tiles[p.tile_offset + blockIdx.x];
     float e[3];
-    if (t.aux == AUX_NONE)
-        run_tile<AUX_NONE, NW, RF, RYMAX>(p, t, raw, e);
-    else if (t.aux == AUX_PX)
-        run_tile<AUX_PX, NW, RB, RYMAX>(p, t, raw, e);
-    else if (t.aux == AUX_PY)
-        run_tile<AUX_PY, NW, RB, RYMAX>(p, t, raw, e);
-    else
-        run_tile<AUX_ALL, NW, RP, RYMAX>(p, t, raw, e);
+    // smallest instantiated superset of the features this tile needs (block-uniform dispatch); AUX_NONE tiles never
+    // touch the boundary (fused_plan.h), boundary tiles always get the source code (3 flops per cell-stage)
+    const int fl = tile_flags(p, t);
+    constexpr int F_ES = F_EDGE | F_SRC, F_CS = F_CYL | F_SRC;
+    if (t.aux == AUX_NONE) {
+        if (fl == 0) run_tile<AUX_NONE, 0, NW, RF, RYMAX>(p, t, raw, e);
+        else if (fl == F_SRC) run_tile<AUX_NONE, F_SRC, NW, RF, RYMAX>(p, t, raw, e);
+        else run_tile<AUX_NONE, F_CS, NW, RF, RYMAX>(p, t, raw, e);
+    } else if (t.aux == AUX_PX) {
+        if (!(fl & F_CYL)) run_tile<AUX_PX, F_ES, NW, RB, RYMAX>(p, t, raw, e);
+        else run_tile<AUX_PX, F_ALL, NW, RB, RYMAX>(p, t, raw, e);
+    } else if (t.aux == AUX_PY) {
+        if (fl == 0) run_tile<AUX_PY, 0, NW, RB, RYMAX>(p, t, raw, e);
+        else if (!(fl & F_CYL)) run_tile<AUX_PY, F_ES, NW, RB, RYMAX>(p, t, raw, e);
+        else run_tile<AUX_PY, F_ALL, NW, RB, RYMAX>(p, t, raw, e);
+    } else {
+        if (!(fl & F_CYL)) run_tile<AUX_ALL, F_ES, NW, RP, RYMAX>(p, t, raw, e);
+        else run_tile<AUX_ALL, F_ALL, NW, RP, RYMAX>(p, t, raw, e);
+    }
     if (p.epart) {  // block-uniform
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -167,6 +179,11 @@ struct FusedPlan {
     int *d_flag = nullptr;
     const Cyl *d_table = nullptr;
     int M = 0;
+    int nbands = 1;               // tile bands per step in graph mode (WAVES_AMD_FUSED_BANDS)
+    bool use_graph = true;        // WAVES_AMD_FUSED_GRAPH=0 disables
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    std::vector<char> graph_key;  // everything the cached graph's kernel arguments were built from
     unsigned long long *d_stamps = nullptr;  // diagnostic (WAVES_AMD_STAMPS=<file>)
     size_t stamps_cap = 0;
     const char *stamps_path = nullptr;
@@ -181,11 +198,11 @@ FusedPlan *fused_create(const Grid &g, const float *x, const float *y, const flo
     p->y.assign(y, y + g.ny);
     p->sx.assign(sx, sx + g.nx);
     p->sy.assign(sy, sy + g.ny);
-    if (const char *e = getenv("WAVES_AMD_FUSED_TILES")) {  // tuning knob: "RF,RB,RP", see fused_launch for the set
+    if (const char *e = getenv("WAVES_AMD_FUSED_TILES")) {  // tuning knob: "RF,RB,RP" in {4,3,2 | 2,2,2}
         int a = 0, b = 0, c = 0;
         if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) {
             const int key = a * 100 + b * 10 + c;
-            if (key == 432 || key == 332 || key == 322 || key == 222 || key == 333 || key == 422) {
+            if (key == 432 || key == 222) {
                 p->RF = a;
                 p->RB = b;
                 p->RP = c;
@@ -194,6 +211,8 @@ FusedPlan *fused_create(const Grid &g, const float *x, const float *y, const flo
     }
     if (const char *e = getenv("WAVES_AMD_FUSED_XCD")) p->xcd_aware = atoi(e) != 0;
     p->stamps_path = getenv("WAVES_AMD_STAMPS");
+    if (const char *e = getenv("WAVES_AMD_FUSED_BANDS")) p->nbands = atoi(e) > 0 ? atoi(e) : 1;
+    if (const char *e = getenv("WAVES_AMD_FUSED_GRAPH")) p->use_graph = atoi(e) != 0;
     if (hipMalloc((void **)&p->d_flag, sizeof(int)) != hipSuccess) {
         delete p;
         return nullptr;
@@ -209,6 +228,8 @@ void fused_destroy(FusedPlan *p)
     if (p->d_flag) (void)hipFree(p->d_flag);
     if (p->d_stamps) (void)hipFree(p->d_stamps);
     if (p->d_src_flags) (void)hipFree(p->d_src_flags);
+    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+    if (p->graph) (void)hipGraphDestroy(p->graph);
     delete p;
 }
 
@@ -238,7 +259,7 @@ static bool ensure_tiles(FusedPlan *p, bool aux_zero)
 {
     if (p->tiles_valid && p->tiles_aux_zero == aux_zero) return true;
     if (!plan_build_tiles(p->hp, p->g.nx, p->g.ny, p->NW * p->RF, p->NW * p->RB, p->NW * p->RP, p->x.data(),
-                          p->y.data(), p->sx.data(), p->sy.data(), aux_zero, p->xcd_aware))
+                          p->y.data(), p->sx.data(), p->sy.data(), aux_zero, p->xcd_aware, p->nbands))
         return false;
     p->src_dirty = true;
     p->tiles_valid = true;
@@ -326,7 +347,7 @@ int fused_prepare(FusedPlan *p, float *frames, float *scratch0, float *scratch1,
     return 0;
 }
 
-void fused_launch(FusedPlan *pl, const FusedStep &st, hipStream_t s)
+static FusedParams make_params(FusedPlan *pl, const FusedCall &call, int step, const FusedStep &st)
 {
     const Grid &g = pl->g;
     FusedParams p{};
@@ -342,16 +363,16 @@ void fused_launch(FusedPlan *pl, const FusedStep &st, hipStream_t s)
     p.c0sq = g.c0sq;
     p.u = st.u;
     p.out = st.out;
-    p.G = st.G;
-    p.src_flags = st.G ? pl->d_src_flags : nullptr;
-    p.sfac[0] = st.sfac[0];
-    p.sfac[1] = st.sfac[1];
-    p.sfac[2] = st.sfac[2];
-    p.cyl = pl->d_table + (size_t)st.table_row * pl->M;
+    p.G = call.G;
+    p.src_flags = call.G ? pl->d_src_flags : nullptr;
+    p.step = step;
+    p.sfac_tab = call.G ? call.d_sfac : nullptr;
+    p.cyl_tab = pl->d_table;
     p.M = pl->M;
-    p.dt = st.dt;
-    p.hdt = 0.5f * st.dt;
+    p.dt = call.dt;
+    p.hdt = 0.5f * call.dt;
     p.tiles = pl->d_tiles;
+    p.tile_offset = 0;
     p.cyl_idx = pl->d_idx;
     p.epart = st.epart;
     p.traj_tot = st.traj_tot;
@@ -366,16 +387,91 @@ void fused_launch(FusedPlan *pl, const FusedStep &st, hipStream_t s)
         }
         p.stamps = pl->d_stamps;
     }
-    const dim3 grid((unsigned)pl->hp.tiles.size());
-    const int key = pl->RF * 100 + pl->RB * 10 + pl->RP;
-    switch (key) {
-        case 332: hipLaunchKernelGGL((k_step_fused<8, 3, 3, 2>), grid, dim3(512), 0, s, p); break;
-        case 322: hipLaunchKernelGGL((k_step_fused<8, 3, 2, 2>), grid, dim3(512), 0, s, p); break;
-        case 222: hipLaunchKernelGGL((k_step_fused<8, 2, 2, 2>), grid, dim3(512), 0, s, p); break;
-        case 333: hipLaunchKernelGGL((k_step_fused<8, 3, 3, 3>), grid, dim3(512), 0, s, p); break;
-        case 422: hipLaunchKernelGGL((k_step_fused<8, 4, 2, 2>), grid, dim3(512), 0, s, p); break;
-        default: hipLaunchKernelGGL((k_step_fused<8, 4, 3, 2>), grid, dim3(512), 0, s, p); break;
+    return p;
+}
+
+static const void *kernel_ptr(const FusedPlan *pl)
+{
+    switch (pl->RF * 100 + pl->RB * 10 + pl->RP) {
+        case 222: return (const void *)k_step_fused<8, 2, 2, 2>;
+        default: return (const void *)k_step_fused<8, 4, 3, 2>;
     }
+}
+
+void fused_launch(FusedPlan *pl, const FusedCall &call, int step, const FusedStep &st, hipStream_t s)
+{
+    FusedParams p = make_params(pl, call, step, st);
+    void *args[1] = {&p};
+    // WAVES_AMD_FUSED_PADLDS (diagnostic): extra dynamic LDS per block, to force one block per CU in occupancy studies
+    static const size_t pad = getenv("WAVES_AMD_FUSED_PADLDS") ? (size_t)atoi(getenv("WAVES_AMD_FUSED_PADLDS")) : 0;
+    (void)hipLaunchKernel(kernel_ptr(pl), dim3((unsigned)pl->hp.tiles.size()), dim3(512), args, pad, s);
+}
+
+template <class T>
+static void key_put(std::vector<char> &k, const T &v)
+{
+    const char *b = reinterpret_cast<const char *>(&v);
+    k.insert(k.end(), b, b + sizeof(T));
+}
+
+int fused_run(FusedPlan *pl, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s)
+{
+    if (!pl->use_graph || pl->stamps_path) {
+        for (int i = 0; i < nsteps; ++i) fused_launch(pl, call, i, steps[i], s);
+        return hipGetLastError() == hipSuccess ? 0 : 1;
+    }
+    // the graph's kernel arguments are functions of exactly these values: rebuild only when one of them changes
+    std::vector<char> key;
+    key_put(key, pl->generation);
+    key_put(key, nsteps);
+    key_put(key, call);
+    key_put(key, pl->d_table);
+    key_put(key, pl->M);
+    key_put(key, pl->d_tiles);
+    key_put(key, pl->d_idx);
+    key_put(key, pl->d_src_flags);
+    key_put(key, pl->nbands);
+    for (int i = 0; i < nsteps; ++i) key_put(key, steps[i]);
+    if (!pl->graph_exec || key != pl->graph_key) {
+        if (pl->graph_exec) (void)hipGraphExecDestroy(pl->graph_exec);
+        if (pl->graph) (void)hipGraphDestroy(pl->graph);
+        pl->graph_exec = nullptr;
+        pl->graph = nullptr;
+        pl->graph_key.clear();
+        if (hipGraphCreate(&pl->graph, 0) != hipSuccess) return 1;
+        const int B = (int)pl->hp.band_begin.size() - 1;
+        std::vector<hipGraphNode_t> prev(B), cur(B);
+        const void *fn = kernel_ptr(pl);
+        for (int i = 0; i < nsteps; ++i) {
+            for (int b = 0; b < B; ++b) {
+                FusedParams p = make_params(pl, call, i, steps[i]);
+                p.tile_offset = pl->hp.band_begin[b];
+                void *args[1] = {&p};
+                hipKernelNodeParams kp{};
+                kp.func = const_cast<void *>(fn);
+                kp.gridDim = dim3((unsigned)(pl->hp.band_begin[b + 1] - pl->hp.band_begin[b]));
+                kp.blockDim = dim3(512);
+                kp.sharedMemBytes = 0;
+                kp.kernelParams = args;
+                kp.extra = nullptr;
+                // a band's tiles read halo cells of the adjacent bands only, and overwrite a buffer whose last readers
+                // were those same three kernels of the previous step
+                hipGraphNode_t deps[3];
+                int nd = 0;
+                if (i > 0)
+                    for (int d = b - 1; d <= b + 1; ++d)
+                        if (d >= 0 && d < B) deps[nd++] = prev[d];
+                if (hipGraphAddKernelNode(&cur[b], pl->graph, nd ? deps : nullptr, nd, &kp) != hipSuccess) return 1;
+            }
+            prev = cur;
+        }
+        if (hipGraphInstantiate(&pl->graph_exec, pl->graph, nullptr, nullptr, 0) != hipSuccess) {
+            pl->graph_exec = nullptr;
+            return 1;
+        }
+        pl->graph_key = key;
+    }
+    return hipGraphLaunch(pl->graph_exec, s) == hipSuccess ? 0 : 1;
 }
 
 int fused_generation(const FusedPlan *p) { return p->generation; }
