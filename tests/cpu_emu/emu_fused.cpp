@@ -37,11 +37,30 @@ static void run_tile(const FusedParams &p, const TileDesc &t, double esum[3])
     std::vector<FusedRegs<AUX, RPT>> regs(NT);
     std::vector<TileCtx> cx(NT);
     for (int tid = 0; tid < NT; ++tid) fused_load<AUX, FL, NW, RPT>(p, t, tid, lds, cx[tid], regs[tid]);
-#define STAGE(S)                                                                                                \
-    for (int tid = 0; tid < NT; ++tid) fused_publish<AUX, FL, NW, RPT, S>(p, t, tid, lds, cx[tid], regs[tid]);  \
-    for (int tid = 0; tid < NT; ++tid) fused_compute<AUX, FL, NW, RPT, S>(p, t, tid, lds, cx[tid], regs[tid]);
-    STAGE(1) STAGE(2) STAGE(3) STAGE(4)
+    for (int tid = 0; tid < NT; ++tid) fused_publish<AUX, FL, NW, RPT, 1>(p, t, tid, lds, cx[tid], regs[tid]);
+    // Between two barriers the waves of a block run in any order and at any relative speed, while the 64 lanes of one
+    // wave run in lock-step.  The emulation runs whole waves one after the other in a tile- and stage-dependent order:
+    // a wave's compute(S) for all its lanes (neighbour lanes are read as the DPP shifts would), then -- with no barrier
+    // in between unless the variant has one -- its publish(S+1), so a wave that "runs ahead" overwrites whatever it is
+    // allowed to overwrite before the slower waves have read the current stage.
+#define STAGE(S)                                                                                                      \
+    for (int k = 0; k < NW; ++k) {                                                                                    \
+        const int w = (5 * k + 3 * S + t.slot) % NW;                                                                  \
+        for (int l = 0; l < 64; ++l)                                                                                  \
+            fused_compute<AUX, FL, NW, RPT, S>(p, t, w * 64 + l, lds, cx[w * 64 + l], regs[w * 64 + l], &regs[w * 64]); \
+        if (!((FL & F_EDGE) && !lds_side_double(NW * RPT, RYMAX)))                                                    \
+            for (int l = 0; l < 64; ++l)                                                                              \
+                fused_publish<AUX, FL, NW, RPT, S + 1>(p, t, w * 64 + l, lds, cx[w * 64 + l], regs[w * 64 + l]);      \
+    }                                                                                                                 \
+    if ((FL & F_EDGE) && !lds_side_double(NW * RPT, RYMAX))                                                           \
+        for (int tid = 0; tid < NT; ++tid) fused_publish<AUX, FL, NW, RPT, S + 1>(p, t, tid, lds, cx[tid], regs[tid]);
+    STAGE(1) STAGE(2) STAGE(3)
 #undef STAGE
+    for (int k = 0; k < NW; ++k) {
+        const int w = (3 * k + t.slot) % NW;
+        for (int l = 0; l < 64; ++l)
+            fused_compute<AUX, FL, NW, RPT, 4>(p, t, w * 64 + l, lds, cx[w * 64 + l], regs[w * 64 + l], &regs[w * 64]);
+    }
     for (int tid = 0; tid < NT; ++tid) {
         float e[3];
         fused_store<AUX, NW, RPT>(p, t, tid, regs[tid], e);

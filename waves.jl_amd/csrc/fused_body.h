@@ -11,9 +11,12 @@
 //   thread  : lane l of wave w owns the RPT cells (l, w + NW*r), r = 0..RPT-1 -- rows dealt round-robin so that the
 //             shrinking set of rows a stage still needs is spread evenly over the waves
 //   stage s : k_s is formed on the region shrunk by s cells; its inputs y_s are needed one cell further out
-//   LDS     : the three fields whose NEIGHBOURS a stage reads (W = U + f, Vx, Vy), as (total, incident) pairs so one
-//             ds_read_b64 serves both wave sets; everything else (u, the RK accumulator, the PML auxiliaries) stays in
-//             registers for the whole step
+//   x nbrs  : lane = x, so the x-neighbours of a cell sit in the adjacent lanes of the same wave: they are fetched with
+//             DPP wave shifts (v_mov/v_sub .. wave_shr:1 / wave_shl:1), never through LDS
+//   LDS     : only the two fields whose Y-neighbours a stage reads (W = U + f and Vy), as (total, incident) pairs so one
+//             ds_read_b64 serves both wave sets, double-buffered so that a stage's results are published for the next
+//             stage while slower waves still read the current one (one barrier per stage); everything else (u, the RK
+//             accumulator, Vx, the PML auxiliaries) stays in registers for the whole step
 //
 // Field sets (template parameter AUX, block-uniform, chosen per tile on the host).  A PML auxiliary field whose
 // damping coefficient is zero over the tile's region stays exactly zero when it starts at zero
@@ -36,7 +39,7 @@ namespace wv {
 
 constexpr int FT_X = 64;         // region width
 constexpr int FT_H = 4;          // halo = number of RK stages
-constexpr int FT_LX = FT_X + 2;  // LDS row length: one guard cell each side, so lanes 0 / 63 read x-1 / x+1 unbranched
+constexpr int FT_LX = FT_X;      // LDS row length (x-neighbours never come from LDS, so no guard columns)
 
 enum : int { AUX_NONE = 0, AUX_PX = 1, AUX_PY = 2, AUX_ALL = 3 };
 enum : int { EDGE_L = 1, EDGE_R = 2, EDGE_T = 4, EDGE_B = 8 };  // region contains gx = 0 / nx-1 / gy = 0 / ny-1
@@ -80,27 +83,46 @@ struct FusedParams {
 };
 
 // LDS image of one tile, carved out of one raw buffer (the kernel instantiates field sets with different RY over the
-// same allocation): three (RY + 2) x FT_LX arrays of (total, incident) pairs, then the boundary side buffers.
+// same allocation): two buffers of two (RY + 2) x FT_LX arrays of (total, incident) pairs (one guard row above and
+// below), then the boundary side buffers and the staged cylinders.
 constexpr int FT_MAXCYL = 32;    // cylinders of one tile staged in LDS (more: read from global memory)
 
 struct FusedLds {
-    F2 *W, *Vx, *Vy;
-    F2 *XL, *XR;  // [row][3 cells][W, Vx]   raw values at gx = 0,1,2 / nx-3,nx-2,nx-1
-    F2 *YT, *YB;  // [3 rows][lane][W, Vy]   raw values at gy = 0,1,2 / ny-3,ny-2,ny-1
-    Cyl *cyl;     // [3 stage times][cyl_count] the tile's culled cylinders
+    F2 *W[2], *Vy[2];    // [stage parity]: stage S reads buffer (S-1)&1 and publishes stage S+1 into buffer S&1
+    F2 *XL[2], *XR[2];   // [parity][row][3 cells][W, Vx]   raw values at gx = 0,1,2 / nx-3,nx-2,nx-1
+    F2 *YT[2], *YB[2];   // [parity][3 rows][lane][W, Vy]   raw values at gy = 0,1,2 / ny-3,ny-2,ny-1
+    Cyl *cyl;            // [3 stage times][cyl_count] the tile's culled cylinders
 };
-constexpr int lds_main_elems(int RY) { return 3 * (RY + 2) * FT_LX; }
+constexpr int lds_main_elems(int RY) { return 2 * (RY + 2) * FT_LX; }  // one buffer
 constexpr int lds_side_elems(int RYMAX) { return 2 * RYMAX * 6 + 2 * 3 * FT_X * 2; }
-constexpr int lds_elems(int RYMAX) { return lds_main_elems(RYMAX) + lds_side_elems(RYMAX) + 3 * FT_MAXCYL * 2; }
+constexpr int lds_elems(int RYMAX) { return 2 * lds_main_elems(RYMAX) + lds_side_elems(RYMAX) + 3 * FT_MAXCYL * 2; }
+// Boundary tiles are never the tallest ones, so their two (smaller) main buffers leave room for a second set of side
+// buffers inside the same allocation: the side copies are then double-buffered like the main arrays and a boundary
+// tile needs no extra barrier.  (When a configuration gives boundary tiles the full height, they fall back to one set
+// plus a barrier between the two halves of a stage.)
+constexpr bool lds_side_double(int RY, int RYMAX) { return 2 * lds_main_elems(RY) + lds_side_elems(RYMAX) <= 2 * lds_main_elems(RYMAX); }
 WV_HD FusedLds lds_view(F2 *raw, int RY, int RYMAX)
 {
-    F2 *side = raw + lds_main_elems(RYMAX);
-    return FusedLds{raw, raw + (RY + 2) * FT_LX, raw + 2 * (RY + 2) * FT_LX,
-                    side, side + RYMAX * 6, side + 2 * RYMAX * 6, side + 2 * RYMAX * 6 + 3 * FT_X * 2,
-                    reinterpret_cast<Cyl *>(side + lds_side_elems(RYMAX))};
+    F2 *b1 = raw + lds_main_elems(RY);
+    F2 *side0 = raw + 2 * lds_main_elems(RYMAX);
+    F2 *side1 = lds_side_double(RY, RYMAX) ? raw + 2 * lds_main_elems(RY) : side0;
+    FusedLds l;
+    l.W[0] = raw;
+    l.Vy[0] = raw + (RY + 2) * FT_LX;
+    l.W[1] = b1;
+    l.Vy[1] = b1 + (RY + 2) * FT_LX;
+    F2 *sd[2] = {side0, side1};
+    for (int k = 0; k < 2; ++k) {
+        l.XL[k] = sd[k];
+        l.XR[k] = sd[k] + RYMAX * 6;
+        l.YT[k] = sd[k] + 2 * RYMAX * 6;
+        l.YB[k] = sd[k] + 2 * RYMAX * 6 + 3 * FT_X * 2;
+    }
+    l.cyl = reinterpret_cast<Cyl *>(side0 + lds_side_elems(RYMAX));
+    return l;
 }
 
-WV_HD int lds_at(int lx, int ly) { return (ly + 1) * FT_LX + (lx + 1); }
+WV_HD int lds_at(int lx, int ly) { return (ly + 1) * FT_LX + lx; }
 
 constexpr int aux_ns(int AUX) { return AUX == AUX_NONE ? 3 : (AUX == AUX_ALL ? 6 : 4); }
 // state plane (within one wave set) of local field j
@@ -113,7 +135,8 @@ struct FusedRegs {
     float acc[RPT][2][NS];  // k1 + 2k2 + 2k3
     float y[RPT][2][NS];    // input of stages 2..4; after stage 4 the new state
     float g[RPT];           // source shape at the cell
-    float b[RPT];           // c^2 of the total set at the current stage time
+    float px[RPT][4];       // cp*W (total, incident), cp*Vx (total, incident) of the current stage input: what the
+                            // x-neighbour lanes read through DPP
     float sx;               // sigma_x of the column
     float xs;               // x coordinate of the column (tiles with cylinders only)
 };
@@ -157,21 +180,76 @@ WV_HD void speed_accum(const Cyl c, float x, float y, int &count, float &cd)
     cd = cd + (in ? c.c : 0.0f);
 }
 
-WV_HD float tile_speed(const FusedParams &p, const TileDesc &t, const TileCtx &cx, const FusedLds &lds, int q, float x,
-                       float y)
+// c^2 of the total set for the RPT rows of one thread at stage time q.  The loop over the tile's cylinders is the
+// OUTER loop (one broadcast LDS read per cylinder and stage instead of one per row); each row still accumulates its
+// cylinders in ascending order, exactly like sum(mask .* c, dims = 3).
+template <int NW, int RPT>
+WV_HD void tile_speed_sq(const FusedParams &p, const TileDesc &t, const TileCtx &cx, const FusedLds &lds, int q, int w,
+                         float x, float bsq[RPT])
 {
-    int count = 0;
-    float cd = 0.0f;
+    int count[RPT];
+    float cd[RPT], ys[RPT];
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) {
+        const int gy = t.y0 - FT_H + w + NW * rr;
+        ys[rr] = p.y[gy < 0 ? 0 : (gy >= p.ny ? p.ny - 1 : gy)];
+        count[rr] = 0;
+        cd[rr] = 0.0f;
+    }
     if (cx.cyl_lds) {
         const Cyl *row = lds.cyl + q * t.cyl_count;
-        for (int k = 0; k < t.cyl_count; ++k) speed_accum(row[k], x, y, count, cd);
+        for (int k = 0; k < t.cyl_count; ++k) {
+            const Cyl c = row[k];
+#pragma unroll
+            for (int rr = 0; rr < RPT; ++rr) speed_accum(c, x, ys[rr], count[rr], cd[rr]);
+        }
     } else {
         const Cyl *row = p.cyl_tab + (size_t)(3 * p.step + q) * p.M;
         const int n = t.cyl_count < 0 ? p.M : t.cyl_count;
-        for (int k = 0; k < n; ++k) speed_accum(row[t.cyl_count < 0 ? k : p.cyl_idx[t.cyl_begin + k]], x, y, count, cd);
+        for (int k = 0; k < n; ++k) {
+            const Cyl c = row[t.cyl_count < 0 ? k : p.cyl_idx[t.cyl_begin + k]];
+#pragma unroll
+            for (int rr = 0; rr < RPT; ++rr) speed_accum(c, x, ys[rr], count[rr], cd[rr]);
+        }
     }
-    const float C0 = count == 0 ? p.c0 : 0.0f;
-    return C0 + cd;
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) {
+        const float c = (count[rr] == 0 ? p.c0 : 0.0f) + cd[rr];  // C(t)   src/env.jl:99, src/designs.jl:110-116
+        bsq[rr] = c * c;                                           // c .^ 2 src/dynamics.jl:159
+    }
+}
+
+// Value of `v` in the lane to the left / right of this one (the cell at x-1 / x+1 of the same row).  On the device `nb`
+// is the thread's own register struct and the value moves by a DPP wave shift (lane 0 / 63 receive 0: those lanes are
+// halo cells whose results nobody reads); in the CPU emulation `nb` points at lane 0 of the wave's 64 register structs.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float wv_dpp_from_left(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wv_dpp_from_right(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+#endif
+
+template <class R>
+WV_HD float px_left(const R *nb, int lane, int rr, int k)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return wv_dpp_from_left(nb->px[rr][k]);
+#else
+    return lane > 0 ? nb[lane - 1].px[rr][k] : 0.0f;
+#endif
+}
+template <class R>
+WV_HD float px_right(const R *nb, int lane, int rr, int k)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return wv_dpp_from_right(nb->px[rr][k]);
+#else
+    return lane < 63 ? nb[lane + 1].px[rr][k] : 0.0f;
+#endif
 }
 
 // ---- phase 0: global -> registers ---------------------------------------------------------------------------
@@ -206,7 +284,6 @@ WV_HD void fused_load(const FusedParams &p, const TileDesc &t, int tid, const Fu
         const int cgy = gy < 0 ? 0 : (gy >= p.ny ? p.ny - 1 : gy);
         const unsigned id = (unsigned)cgy * (unsigned)p.nx + (unsigned)cgx;
         r.g[rr] = ((FL & F_SRC) && cx.has_src && in) ? p.G[id] : 0.0f;
-        r.b[rr] = p.c0sq;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -218,10 +295,12 @@ WV_HD void fused_load(const FusedParams &p, const TileDesc &t, int tid, const Fu
 }
 
 // ---- phase "publish": the stage input's stencil fields -> LDS ------------------------------------------------
+// (stage S's inputs go to LDS buffer (S-1)&1; the x-neighbour values stay in the thread's px registers)
 template <int AUX, int FL, int NW, int RPT, int S>
 WV_HD void fused_publish(const FusedParams &p, const TileDesc &t, int tid, const FusedLds &lds, const TileCtx &cx,
-                         const FusedRegs<AUX, RPT> &r)
+                         FusedRegs<AUX, RPT> &r)
 {
+    constexpr int BUF = (S - 1) & 1;
     const int lane = tid & 63, w = tid >> 6;
     const int rows = t.oy + 2 * FT_H;
     const float sf = cx.sf[stage_q(S)];
@@ -239,26 +318,29 @@ WV_HD void fused_publish(const FusedParams &p, const TileDesc &t, int tid, const
             wi = wi + f;
         }
         const int i = lds_at(lane, ly);
-        lds.W[i] = F2{cp * wt, cp * wi};
-        lds.Vx[i] = F2{cp * yin[0][1], cp * yin[1][1]};
-        lds.Vy[i] = F2{cp * yin[0][2], cp * yin[1][2]};
+        r.px[rr][0] = cp * wt;
+        r.px[rr][1] = cp * wi;
+        r.px[rr][2] = cp * yin[0][1];
+        r.px[rr][3] = cp * yin[1][1];
+        lds.W[BUF][i] = F2{r.px[rr][0], r.px[rr][1]};
+        lds.Vy[BUF][i] = F2{cp * yin[0][2], cp * yin[1][2]};
         if ((FL & F_EDGE) && t.edge) {  // block-uniform: raw copies of the three cells next to a domain boundary
             const int gy = t.y0 - FT_H + ly;
             if ((t.edge & EDGE_L) && gx >= 0 && gx < 3) {
-                lds.XL[(ly * 3 + gx) * 2 + 0] = F2{wt, wi};
-                lds.XL[(ly * 3 + gx) * 2 + 1] = F2{yin[0][1], yin[1][1]};
+                lds.XL[BUF][(ly * 3 + gx) * 2 + 0] = F2{wt, wi};
+                lds.XL[BUF][(ly * 3 + gx) * 2 + 1] = F2{yin[0][1], yin[1][1]};
             }
             if ((t.edge & EDGE_R) && gx >= p.nx - 3 && gx < p.nx) {
-                lds.XR[(ly * 3 + (gx - (p.nx - 3))) * 2 + 0] = F2{wt, wi};
-                lds.XR[(ly * 3 + (gx - (p.nx - 3))) * 2 + 1] = F2{yin[0][1], yin[1][1]};
+                lds.XR[BUF][(ly * 3 + (gx - (p.nx - 3))) * 2 + 0] = F2{wt, wi};
+                lds.XR[BUF][(ly * 3 + (gx - (p.nx - 3))) * 2 + 1] = F2{yin[0][1], yin[1][1]};
             }
             if ((t.edge & EDGE_T) && gy >= 0 && gy < 3) {
-                lds.YT[(gy * FT_X + lane) * 2 + 0] = F2{wt, wi};
-                lds.YT[(gy * FT_X + lane) * 2 + 1] = F2{yin[0][2], yin[1][2]};
+                lds.YT[BUF][(gy * FT_X + lane) * 2 + 0] = F2{wt, wi};
+                lds.YT[BUF][(gy * FT_X + lane) * 2 + 1] = F2{yin[0][2], yin[1][2]};
             }
             if ((t.edge & EDGE_B) && gy >= p.ny - 3 && gy < p.ny) {
-                lds.YB[((gy - (p.ny - 3)) * FT_X + lane) * 2 + 0] = F2{wt, wi};
-                lds.YB[((gy - (p.ny - 3)) * FT_X + lane) * 2 + 1] = F2{yin[0][2], yin[1][2]};
+                lds.YB[BUF][((gy - (p.ny - 3)) * FT_X + lane) * 2 + 0] = F2{wt, wi};
+                lds.YB[BUF][((gy - (p.ny - 3)) * FT_X + lane) * 2 + 1] = F2{yin[0][2], yin[1][2]};
             }
         }
     }
@@ -271,17 +353,25 @@ WV_HD F2 one_sided(float c0, float c1, float c2, F2 v0, F2 v1, F2 v2)
 }
 
 // ---- phase "compute": k_S from the LDS image, then the RK update of the registers ----------------------------
+// `nb`: see px_left / px_right.
 template <int AUX, int FL, int NW, int RPT, int S>
 WV_HD void fused_compute(const FusedParams &p, const TileDesc &t, int tid, const FusedLds &lds, const TileCtx &cx,
-                         FusedRegs<AUX, RPT> &r)
+                         FusedRegs<AUX, RPT> &r, const FusedRegs<AUX, RPT> *nb)
 {
     constexpr int NS = aux_ns(AUX);
+    constexpr int BUF = (S - 1) & 1;
     constexpr bool HAS_SX = AUX == AUX_PX || AUX == AUX_ALL;
     constexpr bool HAS_SY = AUX == AUX_PY || AUX == AUX_ALL;
     const int lane = tid & 63, w = tid >> 6;
     const int rows = t.oy + 2 * FT_H;
     const int gx = t.x0 - FT_H + lane;
     const Ops &o = p.ops;
+    // wave speed first: the loop over the tile's cylinders then only has the thread's persistent state live across it
+    // (stage 3 re-evaluates t + dt/2: cheaper than carrying c^2 per row through the barrier)
+    float bsq[RPT];
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) bsq[rr] = p.c0sq;
+    if ((FL & F_CYL) && cx.has_cyl) tile_speed_sq<NW, RPT>(p, t, cx, lds, stage_q(S), w, r.xs, bsq);
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
         const int ly = w + NW * rr;
@@ -289,39 +379,35 @@ WV_HD void fused_compute(const FusedParams &p, const TileDesc &t, int tid, const
         const int gy = t.y0 - FT_H + ly;
         if ((FL & F_EDGE) && (gy < 0 || gy >= p.ny)) continue;
         const int i = lds_at(lane, ly);
-        const F2 Wl = lds.W[i - 1], Wr = lds.W[i + 1], Wd = lds.W[i - FT_LX], Wu = lds.W[i + FT_LX];
-        const F2 Xl = lds.Vx[i - 1], Xr = lds.Vx[i + 1], Yd = lds.Vy[i - FT_LX], Yu = lds.Vy[i + FT_LX];
-        F2 Ux = F2{Wr.x - Wl.x, Wr.y - Wl.y};
+        const F2 Wd = lds.W[BUF][i - FT_LX], Wu = lds.W[BUF][i + FT_LX];
+        const F2 Yd = lds.Vy[BUF][i - FT_LX], Yu = lds.Vy[BUF][i + FT_LX];
+        F2 Ux = F2{px_right(nb, lane, rr, 0) - px_left(nb, lane, rr, 0), px_right(nb, lane, rr, 1) - px_left(nb, lane, rr, 1)};
         F2 Uy = F2{Wu.x - Wd.x, Wu.y - Wd.y};
-        F2 Vxx = F2{Xr.x - Xl.x, Xr.y - Xl.y};
+        F2 Vxx = F2{px_right(nb, lane, rr, 2) - px_left(nb, lane, rr, 2), px_right(nb, lane, rr, 3) - px_left(nb, lane, rr, 3)};
         F2 Vyy = F2{Yu.x - Yd.x, Yu.y - Yd.y};
         bool border = false;
         if ((FL & F_EDGE) && t.edge) {  // block-uniform
             if ((t.edge & EDGE_L) && gx == 0) {
-                const F2 *v = lds.XL + ly * 6;
+                const F2 *v = lds.XL[BUF] + ly * 6;
                 Ux = one_sided(o.f0, o.f1, o.f2, v[0], v[2], v[4]);
                 Vxx = one_sided(o.f0, o.f1, o.f2, v[1], v[3], v[5]);
             }
             if ((t.edge & EDGE_R) && gx == p.nx - 1) {
-                const F2 *v = lds.XR + ly * 6;
+                const F2 *v = lds.XR[BUF] + ly * 6;
                 Ux = one_sided(o.b0, o.b1, o.b2, v[0], v[2], v[4]);
                 Vxx = one_sided(o.b0, o.b1, o.b2, v[1], v[3], v[5]);
             }
             if ((t.edge & EDGE_T) && gy == 0) {
-                const F2 *v = lds.YT + lane * 2;
+                const F2 *v = lds.YT[BUF] + lane * 2;
                 Uy = one_sided(o.f0, o.f1, o.f2, v[0], v[2 * FT_X], v[4 * FT_X]);
                 Vyy = one_sided(o.f0, o.f1, o.f2, v[1], v[2 * FT_X + 1], v[4 * FT_X + 1]);
             }
             if ((t.edge & EDGE_B) && gy == p.ny - 1) {
-                const F2 *v = lds.YB + lane * 2;
+                const F2 *v = lds.YB[BUF] + lane * 2;
                 Uy = one_sided(o.b0, o.b1, o.b2, v[0], v[2 * FT_X], v[4 * FT_X]);
                 Vyy = one_sided(o.b0, o.b1, o.b2, v[1], v[2 * FT_X + 1], v[4 * FT_X + 1]);
             }
             border = gx <= 0 || gy == 0 || gx >= p.nx - 1 || gy == p.ny - 1;
-        }
-        if ((FL & F_CYL) && S != 3 && cx.has_cyl) {  // stage 3 shares t + dt/2 with stage 2
-            const float c = tile_speed(p, t, cx, lds, stage_q(S), r.xs, p.y[gy]);  // C(t)   src/env.jl:99
-            r.b[rr] = c * c;                                                       // c .^ 2 src/dynamics.jl:159
         }
         const float(&yin)[2][NS] = S == 1 ? r.u[rr] : r.y[rr];
         const float sx = r.sx;
@@ -329,7 +415,7 @@ WV_HD void fused_compute(const FusedParams &p, const TileDesc &t, int tid, const
         float k[2][NS];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const float b = (s == 0 && (FL & F_CYL)) ? r.b[rr] : p.c0sq;
+            const float b = (s == 0 && (FL & F_CYL)) ? bsq[rr] : p.c0sq;
             const float ux = s == 0 ? Ux.x : Ux.y, uy = s == 0 ? Uy.x : Uy.y;
             const float vxx = s == 0 ? Vxx.x : Vxx.y, vyy = s == 0 ? Vyy.x : Vyy.y;
             const float U = yin[s][0];

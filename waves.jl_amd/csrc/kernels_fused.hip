@@ -34,18 +34,24 @@ __device__ __forceinline__ void run_tile(const FusedParams &p, const TileDesc &t
     WV_STAMP(0)
     if (st && tid == 0) st[14] = __builtin_amdgcn_s_memrealtime();
     fused_load<AUX, FL, NW, RPT>(p, t, tid, lds, cx, r);
-#define WV_STAGE(S)                                          \
-    fused_publish<AUX, FL, NW, RPT, S>(p, t, tid, lds, cx, r); \
-    __syncthreads();                                         \
-    WV_STAMP(2 * S - 1)                                      \
-    fused_compute<AUX, FL, NW, RPT, S>(p, t, tid, lds, cx, r); \
-    if (S < 4) __syncthreads();                              \
-    WV_STAMP(2 * S)
+    fused_publish<AUX, FL, NW, RPT, 1>(p, t, tid, lds, cx, r);
+    __syncthreads();
+    WV_STAMP(1)
+    // stage S: read buffer (S-1)&1 (+ DPP), update the registers, publish stage S+1 into buffer S&1; one barrier per
+    // stage (boundary tiles whose side buffers cannot be double-buffered separate the two halves with a barrier).
+#define WV_STAGE(S)                                                      \
+    fused_compute<AUX, FL, NW, RPT, S>(p, t, tid, lds, cx, r, &r);       \
+    if ((FL & F_EDGE) && !lds_side_double(NW * RPT, RYMAX)) __syncthreads(); \
+    WV_STAMP(2 * S)                                                      \
+    fused_publish<AUX, FL, NW, RPT, S + 1>(p, t, tid, lds, cx, r);       \
+    __syncthreads();                                                     \
+    WV_STAMP(2 * S + 1)
     WV_STAGE(1)
     WV_STAGE(2)
     WV_STAGE(3)
-    WV_STAGE(4)
 #undef WV_STAGE
+    fused_compute<AUX, FL, NW, RPT, 4>(p, t, tid, lds, cx, r, &r);
+    WV_STAMP(8)
     fused_store<AUX, NW, RPT>(p, t, tid, r, e);
     WV_STAMP(9)
     if (st && tid == 0) {
