@@ -75,24 +75,36 @@ static void run_step(const FusedParams &p, const HostPlan &pl, double esum[3])
     constexpr int RYMAX = NW * RMAX;
     static_assert(RYMAX <= 48, "g_lds_raw too small");
     for (const TileDesc &t : pl.tiles) {
-        const int fl = g_force_all ? F_ALL : tile_flags(p, t);  // the dispatch of k_step_fused
-        constexpr int F_ES = F_EDGE | F_SRC, F_CS = F_CYL | F_SRC;
-        if (t.aux == AUX_NONE) {
-            if (fl == 0) run_tile<AUX_NONE, 0, NW, RF, RYMAX>(p, t, esum);
-            else if (fl == F_SRC) run_tile<AUX_NONE, F_SRC, NW, RF, RYMAX>(p, t, esum);
-            else if (!(fl & F_EDGE)) run_tile<AUX_NONE, F_CS, NW, RF, RYMAX>(p, t, esum);
-            else run_tile<AUX_NONE, F_ALL, NW, RF, RYMAX>(p, t, esum);   // only via force_all (never planned)
-        } else if (t.aux == AUX_PX) {
-            if (!(fl & F_CYL)) run_tile<AUX_PX, F_ES, NW, RB, RYMAX>(p, t, esum);
-            else run_tile<AUX_PX, F_ALL, NW, RB, RYMAX>(p, t, esum);
-        } else if (t.aux == AUX_PY) {
-            if (fl == 0) run_tile<AUX_PY, 0, NW, RB, RYMAX>(p, t, esum);
-            else if (!(fl & F_CYL)) run_tile<AUX_PY, F_ES, NW, RB, RYMAX>(p, t, esum);
-            else run_tile<AUX_PY, F_ALL, NW, RB, RYMAX>(p, t, esum);
-        } else {
-            if (!(fl & F_CYL)) run_tile<AUX_ALL, F_ES, NW, RP, RYMAX>(p, t, esum);
-            else run_tile<AUX_ALL, F_ALL, NW, RP, RYMAX>(p, t, esum);
+#define RUN(A, F, R) run_tile<A, F, NW, R, RYMAX>(p, t, esum)
+        if (g_force_all) {  // every tile through the most general body of its field set: same bits expected
+            if (t.aux == AUX_NONE) RUN(AUX_NONE, F_ALL, RF);
+            else if (t.aux == AUX_PX) RUN(AUX_PX, F_ALL, RB);
+            else if (t.aux == AUX_PY) RUN(AUX_PY, F_ALL, RB);
+            else RUN(AUX_ALL, F_ALL, RP);
+            continue;
         }
+        // the dispatch of k_step_fused
+        const int fl = tile_flags(p, t);
+        const int fe = fl & F_EDGE;
+        const bool cyl = (fl & F_CYL) != 0;
+        if (t.aux == AUX_NONE) {  // never a boundary tile (fused_plan.h)
+            if (fl == 0) RUN(AUX_NONE, 0, RF);
+            else if (fl == F_SRC) RUN(AUX_NONE, F_SRC, RF);
+            else RUN(AUX_NONE, F_CYL | F_SRC, RF);
+        } else if (t.aux == AUX_PX) {
+            if (!cyl && fe == F_EL) RUN(AUX_PX, F_EL | F_SRC, RB);
+            else if (!cyl && fe == F_ER) RUN(AUX_PX, F_ER | F_SRC, RB);
+            else RUN(AUX_PX, F_ALL, RB);
+        } else if (t.aux == AUX_PY) {
+            if (fl == 0) RUN(AUX_PY, 0, RB);
+            else if (!cyl && fe == F_ET) RUN(AUX_PY, F_ET | F_SRC, RB);
+            else if (!cyl && fe == F_EB) RUN(AUX_PY, F_EB | F_SRC, RB);
+            else RUN(AUX_PY, F_ALL, RB);
+        } else {
+            if (!cyl) RUN(AUX_ALL, F_EDGE | F_SRC, RP);
+            else RUN(AUX_ALL, F_ALL, RP);
+        }
+#undef RUN
     }
 }
 

@@ -41,7 +41,7 @@ __device__ __forceinline__ void run_tile(const FusedParams &p, const TileDesc &t
     // stage (boundary tiles whose side buffers cannot be double-buffered separate the two halves with a barrier).
 #define WV_STAGE(S)                                                      \
     fused_compute<AUX, FL, NW, RPT, S>(p, t, tid, lds, cx, r, &r);       \
-    if ((FL & F_EDGE) && !lds_side_double(NW * RPT, RYMAX)) __syncthreads(); \
+    if ((FL & F_EDGE) && !lds_side_double(NW * RPT, RYMAX)) __syncthreads();  \
     WV_STAMP(2 * S)                                                      \
     fused_publish<AUX, FL, NW, RPT, S + 1>(p, t, tid, lds, cx, r);       \
     __syncthreads();                                                     \
@@ -74,25 +74,30 @@ __global__ __launch_bounds__(NW * 64, 4) void k_step_fused(FusedParams p)  // 4 
     __shared__ float red[3][NW];
     const TileDesc t = p.tiles[p.tile_offset + blockIdx.x];
     float e[3];
-    // smallest instantiated superset of the features this tile needs (block-uniform dispatch); AUX_NONE tiles never
-    // touch the boundary (fused_plan.h), boundary tiles always get the source code (3 flops per cell-stage)
+    // smallest instantiated superset of the features this tile needs (block-uniform dispatch): boundary tiles are
+    // specialised per side (left/right strips, bottom/top bands), corners get all four sides
+#define RUN(A, F, R) run_tile<A, F, NW, R, RYMAX>(p, t, raw, e)
     const int fl = tile_flags(p, t);
-    constexpr int F_ES = F_EDGE | F_SRC, F_CS = F_CYL | F_SRC;
-    if (t.aux == AUX_NONE) {
-        if (fl == 0) run_tile<AUX_NONE, 0, NW, RF, RYMAX>(p, t, raw, e);
-        else if (fl == F_SRC) run_tile<AUX_NONE, F_SRC, NW, RF, RYMAX>(p, t, raw, e);
-        else run_tile<AUX_NONE, F_CS, NW, RF, RYMAX>(p, t, raw, e);
+    const int fe = fl & F_EDGE;
+    const bool cyl = (fl & F_CYL) != 0;
+    if (t.aux == AUX_NONE) {  // never a boundary tile (fused_plan.h)
+        if (fl == 0) RUN(AUX_NONE, 0, RF);
+        else if (fl == F_SRC) RUN(AUX_NONE, F_SRC, RF);
+        else RUN(AUX_NONE, F_CYL | F_SRC, RF);
     } else if (t.aux == AUX_PX) {
-        if (!(fl & F_CYL)) run_tile<AUX_PX, F_ES, NW, RB, RYMAX>(p, t, raw, e);
-        else run_tile<AUX_PX, F_ALL, NW, RB, RYMAX>(p, t, raw, e);
+        if (!cyl && fe == F_EL) RUN(AUX_PX, F_EL | F_SRC, RB);
+        else if (!cyl && fe == F_ER) RUN(AUX_PX, F_ER | F_SRC, RB);
+        else RUN(AUX_PX, F_ALL, RB);
     } else if (t.aux == AUX_PY) {
-        if (fl == 0) run_tile<AUX_PY, 0, NW, RB, RYMAX>(p, t, raw, e);
-        else if (!(fl & F_CYL)) run_tile<AUX_PY, F_ES, NW, RB, RYMAX>(p, t, raw, e);
-        else run_tile<AUX_PY, F_ALL, NW, RB, RYMAX>(p, t, raw, e);
+        if (fl == 0) RUN(AUX_PY, 0, RB);
+        else if (!cyl && fe == F_ET) RUN(AUX_PY, F_ET | F_SRC, RB);
+        else if (!cyl && fe == F_EB) RUN(AUX_PY, F_EB | F_SRC, RB);
+        else RUN(AUX_PY, F_ALL, RB);
     } else {
-        if (!(fl & F_CYL)) run_tile<AUX_ALL, F_ES, NW, RP, RYMAX>(p, t, raw, e);
-        else run_tile<AUX_ALL, F_ALL, NW, RP, RYMAX>(p, t, raw, e);
+        if (!cyl) RUN(AUX_ALL, F_EDGE | F_SRC, RP);
+        else RUN(AUX_ALL, F_ALL, RP);
     }
+#undef RUN
     if (p.epart) {  // block-uniform
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -346,8 +351,8 @@ int fused_prepare(FusedPlan *p, float *frames, float *scratch0, float *scratch1,
         hipLaunchKernelGGL(k_src_flags, dim3((unsigned)nt), dim3(256), 0, s, p->d_tiles, G, g.nx, g.ny, p->d_src_flags);
         p->src_dirty = false;
     }
-    // the host vectors are reused by the next prepare: make sure the copies are done with them
-    if (hipStreamSynchronize(s) != hipSuccess) return 1;
+    // (the host vectors the copies above read are members of the plan and are next modified by the next prepare, i.e.
+    // after the caller has waited for this integrate call: no synchronisation needed here)
     p->d_table = d_table;
     p->M = M;
     return 0;

@@ -27,11 +27,21 @@ def _range_f32(start, stop, n: int) -> np.ndarray:
     risky[0] = risky[-1] = False
     out[0], out[-1] = f32(start), f32(stop)
     if risky.any():
-        a, b = Fraction(a64), Fraction(b64)
+        # exact comparison of the rational a + (b-a)*k/(n-1) with the midpoint, in integer arithmetic (every float is an
+        # integer ratio with a power-of-two denominator)
+        an, ad = a64.as_integer_ratio()
+        bn, bd = b64.as_integer_ratio()
         for k in np.nonzero(risky)[0]:
-            q = a + (b - a) * Fraction(int(k), n - 1)
-            cands = [out[k], np.nextafter(out[k], f32(-np.inf)), np.nextafter(out[k], f32(np.inf))]
-            out[k] = min(cands, key=lambda c: abs(Fraction(float(c)) - q))
+            k = int(k)
+            # q = (an/ad)*(n-1-k)/(n-1) + (bn/bd)*k/(n-1)  ->  numerator / denominator
+            qn = an * bd * (n - 1 - k) + bn * ad * k
+            qd = ad * bd * (n - 1)
+            mn, md = float(mid[k]).as_integer_ratio()
+            lhs, rhs = qn * md, mn * qd          # q ? mid   <=>   lhs ? rhs   (qd, md > 0)
+            if lhs == rhs:
+                continue                         # an exact tie: float64 -> float32 already rounded half-to-even
+            lo_, hi_ = (out[k], other[k]) if out[k] < other[k] else (other[k], out[k])
+            out[k] = lo_ if lhs < rhs else hi_
     return out
 
 

@@ -5,6 +5,7 @@ Dirichlet mask and the Runge-Kutta loop all execute as HIP kernels inside libwav
 """
 from __future__ import annotations
 
+import functools
 from typing import Optional, Sequence
 
 import numpy as np
@@ -17,11 +18,18 @@ from .sources import NoSource
 f32 = np.float32
 
 
+@functools.lru_cache(maxsize=4096)
+def _tspan_cached(ti: float, dt: float, steps: int):
+    stop = f32(f32(ti) + f32(f32(steps) * f32(dt)))
+    t = _range_f32(f32(ti), stop, steps + 1)
+    t.setflags(write=False)
+    return t
+
+
 def build_tspan(ti, dt, steps: int) -> np.ndarray:
-    """src/dynamics.jl:5-7: collect(range(ti, ti + steps*dt, steps + 1)) in Float32."""
-    ti = f32(ti)
-    stop = f32(ti + f32(f32(steps) * f32(dt)))
-    return _range_f32(ti, stop, steps + 1)
+    """src/dynamics.jl:5-7: collect(range(ti, ti + steps*dt, steps + 1)) in Float32.  (Memoised: every episode walks
+    through the same (ti, dt, steps) triples.)"""
+    return _tspan_cached(float(f32(ti)), float(f32(dt)), int(steps)).copy()
 
 
 def runge_kutta(*_args, **_kw):
