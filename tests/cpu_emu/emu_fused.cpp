@@ -92,13 +92,13 @@ static void run_step(const FusedParams &p, const HostPlan &pl, double esum[3])
             else if (fl == F_SRC) RUN(AUX_NONE, F_SRC, RF);
             else RUN(AUX_NONE, F_CYL | F_SRC, RF);
         } else if (t.aux == AUX_PX) {
-            if (!cyl && fe == F_EL) RUN(AUX_PX, F_EL | F_SRC, RB);
-            else if (!cyl && fe == F_ER) RUN(AUX_PX, F_ER | F_SRC, RB);
+            if (!cyl && (fe & ~F_EL) == 0) RUN(AUX_PX, F_EL | F_SRC, RB);  // left strip, or a PML strip off the boundary
+            else if (!cyl && (fe & ~F_ER) == 0) RUN(AUX_PX, F_ER | F_SRC, RB);
             else RUN(AUX_PX, F_ALL, RB);
         } else if (t.aux == AUX_PY) {
             if (fl == 0) RUN(AUX_PY, 0, RB);
-            else if (!cyl && fe == F_ET) RUN(AUX_PY, F_ET | F_SRC, RB);
-            else if (!cyl && fe == F_EB) RUN(AUX_PY, F_EB | F_SRC, RB);
+            else if (!cyl && (fe & ~F_ET) == 0) RUN(AUX_PY, F_ET | F_SRC, RB);
+            else if (!cyl && (fe & ~F_EB) == 0) RUN(AUX_PY, F_EB | F_SRC, RB);
             else RUN(AUX_PY, F_ALL, RB);
         } else {
             if (!cyl) RUN(AUX_ALL, F_EDGE | F_SRC, RP);

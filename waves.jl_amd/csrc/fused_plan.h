@@ -250,7 +250,7 @@ inline bool plan_build_tiles(HostPlan &pl, int nx, int ny, int RYF, int RYB, int
 // integrate call.  Conservative bounding boxes with a safety margin far above fp32 round-off: a culled cylinder must
 // have mask == false at every cell of the region, in which case dropping it is exact (it would add +0).
 inline void plan_build_cyl(HostPlan &pl, const float *x, const float *y, const Cyl *table, int M, int rows,
-                           std::vector<int> &idx)
+                           std::vector<int> &idx, bool resort = true)
 {
     idx.clear();
     if (M <= 0) {
@@ -309,7 +309,7 @@ inline void plan_build_cyl(HostPlan &pl, const float *x, const float *y, const C
     // Launch order refinement: inside each XCD group (launch positions congruent modulo 8 -- or all tiles when the order
     // is not XCD-aware) the tiles that will take longest (cylinders to evaluate, more fields) go first: the kernel ends
     // when its slowest tile ends, and launch positions are worth up to ~1 us of head start.
-    for (size_t b = 0; b + 1 < pl.band_begin.size(); ++b) {
+    for (size_t b = 0; resort && b + 1 < pl.band_begin.size(); ++b) {
         const int lo = pl.band_begin[b], hi = pl.band_begin[b + 1];
         for (int g = 0; g < 8; ++g) {
             std::vector<TileDesc> grp;

@@ -85,13 +85,13 @@ __global__ __launch_bounds__(NW * 64, 4) void k_step_fused(FusedParams p)  // 4 
         else if (fl == F_SRC) RUN(AUX_NONE, F_SRC, RF);
         else RUN(AUX_NONE, F_CYL | F_SRC, RF);
     } else if (t.aux == AUX_PX) {
-        if (!cyl && fe == F_EL) RUN(AUX_PX, F_EL | F_SRC, RB);
-        else if (!cyl && fe == F_ER) RUN(AUX_PX, F_ER | F_SRC, RB);
+        if (!cyl && (fe & ~F_EL) == 0) RUN(AUX_PX, F_EL | F_SRC, RB);  // left strip, or a PML strip off the boundary
+        else if (!cyl && (fe & ~F_ER) == 0) RUN(AUX_PX, F_ER | F_SRC, RB);
         else RUN(AUX_PX, F_ALL, RB);
     } else if (t.aux == AUX_PY) {
         if (fl == 0) RUN(AUX_PY, 0, RB);
-        else if (!cyl && fe == F_ET) RUN(AUX_PY, F_ET | F_SRC, RB);
-        else if (!cyl && fe == F_EB) RUN(AUX_PY, F_EB | F_SRC, RB);
+        else if (!cyl && (fe & ~F_ET) == 0) RUN(AUX_PY, F_ET | F_SRC, RB);
+        else if (!cyl && (fe & ~F_EB) == 0) RUN(AUX_PY, F_EB | F_SRC, RB);
         else RUN(AUX_PY, F_ALL, RB);
     } else {
         if (!cyl) RUN(AUX_ALL, F_EDGE | F_SRC, RP);
@@ -319,7 +319,8 @@ int fused_prepare(FusedPlan *p, float *frames, float *scratch0, float *scratch1,
         if (capture) p->frames_clean = false;
     }
     if (!ensure_tiles(p, aux_zero)) return 2;
-    plan_build_cyl(p->hp, p->x.data(), p->y.data(), h_table, M, rows, p->idx);
+    static const bool resort = !(getenv("WAVES_AMD_FUSED_RESORT") && atoi(getenv("WAVES_AMD_FUSED_RESORT")) == 0);
+    plan_build_cyl(p->hp, p->x.data(), p->y.data(), h_table, M, rows, p->idx, resort);
     const size_t nt = p->hp.tiles.size();
     if (nt > p->tiles_cap) {
         if (p->d_tiles) (void)hipFree(p->d_tiles);

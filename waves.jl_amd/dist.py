@@ -24,7 +24,7 @@ def init(backend: str | None = None):
     import torch
     import torch.distributed as dist
     rank, local_rank, world = env_rank()
-    if world == 1:
+    if world == 1 and not os.environ.get("WAVES_AMD_FORCE_DIST"):  # (the variable lets a 1-GPU box exercise the RCCL path)
         return rank, local_rank, world
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -84,7 +84,7 @@ def broadcast_design_space(ds: DesignSpace | None, src: int = 0) -> DesignSpace:
     """Every rank ends up with rank `src`'s design space (one small broadcast; latency-bound)."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return ds
     dev = _device()
     n = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -103,7 +103,7 @@ def broadcast_field(field: np.ndarray | None, shape, src: int = 0) -> np.ndarray
     """Broadcast one (nx, ny) fp32 field (e.g. a design/wave-speed field or a source shape) from rank `src`."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return field
     dev = _device()
     if dist.get_rank() == src:
@@ -118,7 +118,7 @@ def gather_signals(sig: np.ndarray) -> List[np.ndarray] | None:
     """all_gather of each rank's stacked energy traces (same shape on every rank); returns the list on every rank."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return [np.asarray(sig)]
     dev = _device()
     t = torch.from_numpy(np.ascontiguousarray(sig, np.float32)).to(dev)
@@ -130,7 +130,7 @@ def gather_signals(sig: np.ndarray) -> List[np.ndarray] | None:
 def max_over_ranks(x: float) -> float:
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return float(x)
     t = torch.tensor([x], dtype=torch.float64, device=_device())
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -139,7 +139,7 @@ def max_over_ranks(x: float) -> float:
 
 def barrier():
     import torch.distributed as dist
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.barrier()
 
 
