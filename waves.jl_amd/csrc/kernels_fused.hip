@@ -66,8 +66,17 @@ __device__ __forceinline__ void run_tile(const FusedParams &p, const TileDesc &t
 // RF / RB / RP: rows per thread of the AUX_NONE / AUX_PX+AUX_PY / AUX_ALL tiles (a thread of a reduced field set
 // carries less state per cell, so it owns more cells at the same register budget).
 template <int NW, int RF, int RB, int RP>
-__global__ __launch_bounds__(NW * 64, 4) void k_step_fused(FusedParams p)  // 4 waves/SIMD = 2 blocks per CU: <= 128 VGPRs
+__global__ __launch_bounds__(NW * 64, 4) void k_step_fused(FusedParams p_)  // 4 waves/SIMD = 2 blocks per CU: <= 128 VGPRs
 {
+    // The arguments are read where they are used, straight from the kernarg segment (uniform s_loads of invariant
+    // memory), instead of being loaded once at entry: ~50 SGPRs live across the whole variant dispatch cost the
+    // variants SGPR spills and made their codegen depend on each other.
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)p_;
+    const FusedParams &p = *(const FusedParams *)(const void *)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    const FusedParams &p = p_;
+#endif
     constexpr int RMAX = RF > RB ? (RF > RP ? RF : RP) : (RB > RP ? RB : RP);
     constexpr int RYMAX = NW * RMAX;
     __shared__ F2 raw[lds_elems(RYMAX)];
