@@ -77,7 +77,7 @@ typedef struct wv_timing {
     int step_kernel_launches;
     int steps;
     int impl;               /* implementation that ran */
-    int reserved;
+    int resident;           /* 1: all steps ran in ONE launch of the resident kernel (step_kernel_launches == 1) */
 } wv_timing;
 
 int wv_abi_version(void);

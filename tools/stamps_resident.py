@@ -1,0 +1,36 @@
+"""Report of the phase stamps k_steps_resident records for the middle step of a call (WAVES_AMD_STAMPS=<file>)."""
+import sys
+import numpy as np
+
+rows = []
+for line in open(sys.argv[1]):
+    if line.startswith("#"):
+        continue
+    head, tail = line.split("|")
+    h = [int(v) for v in head.split()]
+    t = [int(v) for v in tail.split()]
+    rows.append(h + t)
+a = np.array(rows, dtype=np.int64)
+T = a[:, 8:8 + 6].astype(np.float64) * 10.0  # s_memrealtime ticks of 10 ns -> ns
+polls = a[:, 8 + 6]
+aux = a[:, 6] & 15
+names = {0: "NONE", 1: "PX", 2: "PY", 3: "ALL"}
+t0 = T[:, 0].min()
+print(f"tiles {len(a)}; step start spread {T[:,0].max()-t0:.0f} ns; last refresh end {T[:,5].max()-t0:.0f} ns")
+for k in range(4):
+    m = aux == k
+    if not m.any():
+        continue
+    d = np.diff(T[m], axis=1)
+    print(f"{names[k]:5s} n={m.sum():3d} mean ns: compute={d[:,0].mean():.0f} store={d[:,1].mean():.0f} "
+          f"ack+barrier={d[:,2].mean():.0f} wait={d[:,3].mean():.0f} (max {d[:,3].max():.0f}) refresh={d[:,4].mean():.0f} "
+          f"polls mean {polls[m].mean():.1f} max {polls[m].max()}  step total {(T[m,5]-T[m,0]).mean():.0f}")
+d = np.diff(T, axis=1)
+order = np.argsort(d[:, 3])
+print("tiles with the shortest waits (the ones the others wait for):")
+for i in order[:12]:
+    print(f"  slot {a[i,1]:3d} x0={a[i,2]:3d} y0={a[i,3]:3d} {names[aux[i]]:4s} cyl={a[i,7]:3d} compute={d[i,0]:.0f} store={d[i,1]:.0f} "
+          f"ack={d[i,2]:.0f} wait={d[i,3]:.0f} refresh={d[i,4]:.0f} polls={polls[i]} total={T[i,5]-T[i,0]:.0f}")
+print("wait percentiles ns:", np.percentile(d[:, 3], [0, 10, 50, 90, 100]).round())
+print("compute percentiles ns:", np.percentile(d[:, 0], [0, 10, 50, 90, 100]).round())
+print("refresh percentiles ns:", np.percentile(d[:, 4], [0, 10, 50, 90, 100]).round())

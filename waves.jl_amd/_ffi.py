@@ -34,7 +34,7 @@ class wv_config(C.Structure):
 
 class wv_timing(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("step_kernel_ms", C.c_double), ("step_kernel_launches", C.c_int),
-                ("steps", C.c_int), ("impl", C.c_int), ("reserved", C.c_int)]
+                ("steps", C.c_int), ("impl", C.c_int), ("resident", C.c_int)]
 
 
 _fp = C.POINTER(C.c_float)

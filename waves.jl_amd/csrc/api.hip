@@ -54,6 +54,7 @@ struct wv_ctx {
     float *d_sfac = nullptr;   // per-step source time factors [nsteps][3]
     size_t sfac_cap = 0;
     std::vector<FusedStep> fsteps;
+    int prof_launches = 0, prof_events = 0;  // profiling mode: integrator launches / event pairs of the last call
     float *d_elast = nullptr;  // per-block energy partials of the state the last integrate ended on
     size_t elast_cap = 0;
     int elast_generation = -1;
@@ -650,7 +651,7 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
         float *tts = tt ? tt + (size_t)s * c->P : nullptr;
         float *tis = ti_ ? ti_ + (size_t)s * c->P : nullptr;
         const float *G = c->has_source ? c->d_G : nullptr;
-        if (c->profiling) HIPCHK(c, hipEventRecord(c->kev[2 * (s - 1)], st));
+        if (c->profiling && impl == WV_IMPL_STAGED) HIPCHK(c, hipEventRecord(c->kev[2 * (s - 1)], st));
         if (impl == WV_IMPL_STAGED) {
             StageIO io{};
             io.u = cur;
@@ -675,18 +676,39 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
             FusedStep fs{};
             fs.u = cur;
             fs.out = out;
+            fs.keep = out != c->d_scratch[0] && out != c->d_scratch[1];  // a frame of env.wave
             fs.epart = ep;
             fs.traj_tot = tts;
             fs.traj_inc = tis;
-            if (c->profiling) fused_launch(c->fused, fcall, s - 1, fs, st);  // eager, bracketed by events
-            else c->fsteps.push_back(fs);                                     // launched together below
+            c->fsteps.push_back(fs);  // launched together below
         }
-        if (c->profiling) HIPCHK(c, hipEventRecord(c->kev[2 * (s - 1) + 1], st));
+        if (c->profiling && impl == WV_IMPL_STAGED) HIPCHK(c, hipEventRecord(c->kev[2 * (s - 1) + 1], st));
         cur = out;
     }
+    c->prof_launches = nsteps * (impl == WV_IMPL_STAGED ? 4 : 1);
+    c->prof_events = nsteps;
+    bool resident = false;
     if (impl == WV_IMPL_FUSED && !c->profiling) {
         if (fused_run(c->fused, fcall, c->fsteps.data(), (int)c->fsteps.size(), st) != 0)
             return fail(c, WV_ERR_HIP, std::string("fused_run failed: ") + hipGetErrorString(hipGetLastError()));
+    } else if (impl == WV_IMPL_FUSED) {
+        // profiling: the single resident launch bracketed by one pair of events, else every step by its own pair
+        // (the events recorded inside the loop above are re-recorded here in stream order)
+        HIPCHK(c, hipEventRecord(c->kev[0], st));
+        const int rr = fused_try_resident(c->fused, fcall, c->fsteps.data(), (int)c->fsteps.size(), st);
+        if (rr > 0) return fail(c, WV_ERR_HIP, std::string("fused_try_resident failed: ") + hipGetErrorString(hipGetLastError()));
+        if (rr == 0) {
+            HIPCHK(c, hipEventRecord(c->kev[1], st));
+            c->prof_launches = 1;
+            c->prof_events = 1;
+            resident = true;
+        } else {
+            for (int s = 0; s < nsteps; ++s) {
+                HIPCHK(c, hipEventRecord(c->kev[2 * s], st));
+                fused_launch(c->fused, fcall, s, c->fsteps[s], st);
+                HIPCHK(c, hipEventRecord(c->kev[2 * s + 1], st));
+            }
+        }
     }
     HIPCHK(c, hipGetLastError());
     if (want_signal) {
@@ -705,6 +727,7 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     c->timing = wv_timing{};
     c->timing.steps = nsteps;
     c->timing.impl = impl;
+    c->timing.resident = resident || (impl == WV_IMPL_FUSED && !c->profiling && fused_last_resident(c->fused)) ? 1 : 0;
     return WV_OK;
 }
 
@@ -727,15 +750,19 @@ int wv_integrate_end(wv_ctx *c, float *signal, float *u_tot, float *u_inc)
     float ms = 0.0f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->timing.total_ms = ms;
+    if (c->timing.impl == WV_IMPL_FUSED && fused_finish(c->fused, st) != 0)
+        return fail(c, WV_ERR_HIP, "wv_integrate: the resident step kernel gave up waiting for a neighbouring tile "
+                                   "(device shared with another cooperative kernel?); the state is invalid -- "
+                                   "wv_reset / wv_set_state, or WAVES_AMD_FUSED_RESIDENT=0");
     if (c->profiling) {
         double sum = 0.0;
-        for (int s = 0; s < n; ++s) {
+        for (int s = 0; s < c->prof_events; ++s) {
             float k = 0.0f;
             HIPCHK(c, hipEventElapsedTime(&k, c->kev[2 * s], c->kev[2 * s + 1]));
             sum += k;
         }
         c->timing.step_kernel_ms = sum;
-        c->timing.step_kernel_launches = n * (c->timing.impl == WV_IMPL_STAGED ? 4 : 1);
+        c->timing.step_kernel_launches = c->prof_launches;
     }
     return WV_OK;
 }

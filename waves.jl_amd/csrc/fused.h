@@ -11,6 +11,8 @@ struct FusedPlan;
 struct FusedStep {
     const float *u;     // state at the start of the step (12 planes)
     float *out;         // state at the end of the step (12 planes, != u)
+    bool keep;          // somebody reads `out` after the call (a captured frame, the final state): the resident kernel,
+                        // whose tiles carry the state in registers, skips the store of every other step
     float *epart;       // per-tile energy partials [fused_energy_blocks][3] or nullptr
     float *traj_tot;    // optional copies of the new U_tot / U_inc planes
     float *traj_inc;
@@ -43,10 +45,17 @@ int fused_prepare(FusedPlan *p, float *frames, float *scratch0, float *scratch1,
 void fused_source_changed(FusedPlan *p);  // the source shape was replaced
 // one step, eagerly, as a single launch over all tiles (profiling mode brackets these with events)
 void fused_launch(FusedPlan *p, const FusedCall &call, int step, const FusedStep &st, hipStream_t s);
-// all steps of a call: a cached hipGraph of (step, band) kernel nodes with neighbour-band dependencies when enabled
-// (consecutive steps then overlap: one band's load / start-up / write-back hides under another band's compute), else
-// eager launches.  Returns 0 on success.
+// all steps of a call: one launch of the resident kernel when the tiles fit the device at once, else a cached hipGraph of
+// single-step kernel nodes (WAVES_AMD_FUSED_GRAPH=0: eager launches).  Returns 0 on success.
 int fused_run(FusedPlan *p, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s);
+// After the stream has been waited for: 0, or 1 when the resident kernel of the last fused_run abandoned the call (a tile
+// waited in vain for its neighbours -- the state is then invalid; the protocol has been reset).
+int fused_finish(FusedPlan *p, hipStream_t s);
+bool fused_last_resident(const FusedPlan *p);  // the last fused_run took the single-launch path
+// All steps in one cooperative launch of k_steps_resident.  Returns 0 when launched, -1 when this call cannot take that
+// path (more tiles than the device holds at once, a single step, diagnostics ...; the caller then launches step by
+// step), 1 on a HIP error.  fused_run tries this first.
+int fused_try_resident(FusedPlan *p, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s);
 void fused_variant_counts(const FusedPlan *p, int out[4]);  // tiles per field set: NONE, PX, PY, ALL
 
 }  // namespace wv

@@ -33,6 +33,8 @@
 // to that boundary into small side buffers, from which the boundary cell forms the reference's one-sided stencil
 // (src/operators.jl:14-15) and then applies the Dirichlet mask (src/dims.jl:117-124).
 #pragma once
+#include <stdint.h>
+
 #include "types.h"
 
 namespace wv {
@@ -56,19 +58,27 @@ struct TileDesc {
     int pad;
 };
 
+// What differs between the steps of one wv_integrate call.
+struct StepIO {
+    const float *u;   // state at the start of the step (12 planes)
+    float *out;       // state at the end of the step (12 planes, != u); k_steps_resident: nullptr = not wanted in memory
+    float *epart;     // per-tile energy partials [ntiles][3] or nullptr
+    float *traj_tot;  // optional copies of the new U_tot / U_inc planes
+    float *traj_inc;
+    int step;         // integration step of this call, 0-based: row of sfac_tab / cyl_tab
+    int pad;
+};
+
 struct FusedParams {
     int nx, ny;
     unsigned P;       // nx*ny (12*P < 2^31, checked at create: 32-bit element offsets everywhere)
     Ops ops;
     const float *x, *y, *sx, *sy;
     float c0, c0sq;
-    const float *u;   // state at the start of the step
-    float *out;       // state at the end of the step
     const float *G;   // source shape or nullptr (NoSource)
     const unsigned char *src_flags;  // per tile slot: shape != 0 somewhere in the region (nullptr: assume yes)
-    // Per-step scalars live in device tables indexed by `step`, so that the kernel arguments of a given step are the
+    // Per-step scalars live in device tables indexed by the step, so that the kernel arguments of a given step are the
     // same for every wv_integrate call of the same shape (a captured hipGraph can then be replayed unchanged).
-    int step;               // integration step of this call, 0-based
     const float *sfac_tab;  // [nsteps][3]  sin(2f0*pi*t*freq) at t, t + dt/2, t + dt
     const Cyl *cyl_tab;     // [nsteps][3][M] cylinders at the three stage times
     int M;
@@ -76,9 +86,14 @@ struct FusedParams {
     const TileDesc *tiles;
     int tile_offset;  // first tile of this launch (a launch covers one band of tiles)
     const int *cyl_idx;
-    float *epart;     // [ntiles][3] or nullptr
-    float *traj_tot;  // optional copies of the new U_tot / U_inc planes
-    float *traj_inc;
+    StepIO io;        // k_step_fused: the one step of this launch
+    // k_steps_resident: all steps of the call in one launch, every tile resident for the whole call
+    const StepIO *steps;       // [nsteps]; steps[s].u == steps[s-1].out
+    int nsteps;
+    unsigned long long *xch;   // halo exchange: [2 parities][12 planes][P] words of (tag << 32 | value bits)
+    unsigned tag_base;         // the border cells of step s carry the tag tag_base + s + 1
+    int *abort;                // set when a wait gave up: every tile then leaves the kernel
+    int reduced;               // the tiles use reduced field sets (auxiliary fields are zero outside the PML)
     unsigned long long *stamps;  // diagnostic: [ntiles][16] shader-clock stamps per phase, or nullptr (normal runs)
 };
 
@@ -139,6 +154,7 @@ struct FusedRegs {
                             // x-neighbour lanes read through DPP
     float sx;               // sigma_x of the column
     float xs;               // x coordinate of the column (tiles with cylinders only)
+    float bsq[3][RPT];      // c^2 of the total set at the three stage times of the step (variants with F_CYL only)
 };
 
 WV_HD int stage_q(int S) { return S == 1 ? 0 : (S == 4 ? 2 : 1); }  // which of the three stage times a stage uses
@@ -151,6 +167,7 @@ enum : int { F_EL = 1, F_ER = 2, F_ET = 4, F_EB = 8, F_EDGE = 15, F_CYL = 16, F_
 // Block-uniform values fetched once per tile (they live in SGPRs): re-reading them from memory in every phase costs a
 // dependent load per phase on a path whose length is what bounds the kernel.
 struct TileCtx {
+    int step;      // row of the per-step tables
     float sf[3];   // sin(2f0*pi*t*freq) at the three stage times of this step (0 without a source)
     bool has_src;  // the source shape is non-zero somewhere in this tile's region
     bool has_cyl;  // at least one cylinder can reach this tile's region
@@ -204,7 +221,7 @@ WV_HD void tile_speed_sq(const FusedParams &p, const TileDesc &t, const TileCtx 
             for (int rr = 0; rr < RPT; ++rr) speed_accum(c, x, ys[rr], count[rr], cd[rr]);
         }
     } else {
-        const Cyl *row = p.cyl_tab + (size_t)(3 * p.step + q) * p.M;
+        const Cyl *row = p.cyl_tab + (size_t)(3 * cx.step + q) * p.M;
         const int n = t.cyl_count < 0 ? p.M : t.cyl_count;
         for (int k = 0; k < n; ++k) {
             const Cyl c = row[t.cyl_count < 0 ? k : p.cyl_idx[t.cyl_begin + k]];
@@ -252,12 +269,10 @@ WV_HD float px_right(const R *nb, int lane, int rr, int k)
 #endif
 }
 
-// ---- phase 0: global -> registers ---------------------------------------------------------------------------
+// ---- phase 0a: what a tile keeps for all its steps -------------------------------------------------------------
 template <int AUX, int FL, int NW, int RPT>
-WV_HD void fused_load(const FusedParams &p, const TileDesc &t, int tid, const FusedLds &lds, TileCtx &cx,
-                      FusedRegs<AUX, RPT> &r)
+WV_HD void fused_tile_init(const FusedParams &p, const TileDesc &t, int tid, TileCtx &cx, FusedRegs<AUX, RPT> &r)
 {
-    constexpr int NS = aux_ns(AUX);
     const int lane = tid & 63, w = tid >> 6;
     const int gx = t.x0 - FT_H + lane;
     const bool inx = gx >= 0 && gx < p.nx;
@@ -265,17 +280,8 @@ WV_HD void fused_load(const FusedParams &p, const TileDesc &t, int tid, const Fu
     cx.has_src = (FL & F_SRC) ? tile_has_src(p, t) : false;
     cx.has_cyl = (FL & F_CYL) ? (p.M > 0 && t.cyl_count != 0) : false;
     cx.cyl_lds = cx.has_cyl && t.cyl_count > 0 && t.cyl_count <= FT_MAXCYL;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) cx.sf[q] = (cx.has_src && p.sfac_tab) ? p.sfac_tab[3 * p.step + q] : 0.0f;
     r.sx = (AUX == AUX_PX || AUX == AUX_ALL) ? p.sx[cgx] : 0.0f;
-    r.xs = 0.0f;
-    if ((FL & F_CYL) && cx.has_cyl) {  // block-uniform
-        r.xs = p.x[cgx];
-        // stage the culled cylinders of the three stage times in LDS; first read after the first barrier of stage 1
-        if (cx.cyl_lds && tid < 3 * t.cyl_count)
-            lds.cyl[tid] = p.cyl_tab[(size_t)(3 * p.step + tid / t.cyl_count) * p.M +
-                                     p.cyl_idx[t.cyl_begin + tid % t.cyl_count]];
-    }
+    r.xs = ((FL & F_CYL) && cx.has_cyl) ? p.x[cgx] : 0.0f;
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
         const int ly = w + NW * rr;
@@ -284,14 +290,217 @@ WV_HD void fused_load(const FusedParams &p, const TileDesc &t, int tid, const Fu
         const int cgy = gy < 0 ? 0 : (gy >= p.ny ? p.ny - 1 : gy);
         const unsigned id = (unsigned)cgy * (unsigned)p.nx + (unsigned)cgx;
         r.g[rr] = ((FL & F_SRC) && cx.has_src && in) ? p.G[id] : 0.0f;
+    }
+}
+
+// ---- phase 0b: the per-step scalars -----------------------------------------------------------------------------
+// (the cylinder copy in LDS is first read after the first barrier of stage 1 and last read in stage 4: the caller has a
+// barrier between stage 4 of one step and this phase of the next)
+template <int FL>
+WV_HD void fused_step_init(const FusedParams &p, int step, const TileDesc &t, int tid, const FusedLds &lds, TileCtx &cx)
+{
+    cx.step = step;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) cx.sf[q] = (cx.has_src && p.sfac_tab) ? p.sfac_tab[3 * step + q] : 0.0f;
+    if ((FL & F_CYL) && cx.cyl_lds && tid < 3 * t.cyl_count)  // block-uniform up to the thread test
+        lds.cyl[tid] = p.cyl_tab[(size_t)(3 * step + tid / t.cyl_count) * p.M + p.cyl_idx[t.cyl_begin + tid % t.cyl_count]];
+}
+
+// ---- phase 0c: global -> registers --------------------------------------------------------------------------------
+template <int AUX, int NW, int RPT>
+WV_HD void fused_load_state(const FusedParams &p, const float *u, const TileDesc &t, int tid, FusedRegs<AUX, RPT> &r)
+{
+    constexpr int NS = aux_ns(AUX);
+    const int lane = tid & 63, w = tid >> 6;
+    const int gx = t.x0 - FT_H + lane;
+    const bool inx = gx >= 0 && gx < p.nx;
+    const int cgx = gx < 0 ? 0 : (gx >= p.nx ? p.nx - 1 : gx);
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) {
+        const int ly = w + NW * rr;
+        const int gy = t.y0 - FT_H + ly;
+        const bool in = inx && gy >= 0 && gy < p.ny && ly < t.oy + 2 * FT_H;
+        const int cgy = gy < 0 ? 0 : (gy >= p.ny ? p.ny - 1 : gy);
+        const unsigned id = (unsigned)cgy * (unsigned)p.nx + (unsigned)cgx;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
-                const float *plane = p.u + (size_t)(6 * s + aux_plane(AUX, j)) * p.P;
+                const float *plane = u + (size_t)(6 * s + aux_plane(AUX, j)) * p.P;
                 r.u[rr][s][j] = in ? plane[id] : 0.0f;
             }
     }
+}
+
+// ---- halo exchange of k_steps_resident ----------------------------------------------------------------------------
+// A resident tile keeps its own output cells in registers from step to step; what it needs from outside is the halo
+// ring, i.e. the outermost FT_H cells of the neighbouring tiles' outputs.  Those travel through p.xch as 8-byte words
+// carrying the value AND the step tag, written and read with single agent-scope atomic accesses (write-through / served
+// from memory, coherent across the XCDs without cache maintenance): a reader that finds the expected tag has the value
+// -- no flag, no acknowledgement to wait for, no ordering between different words needed.  One buffer per tag parity:
+// a tile can only write the border of step s+2 after it has read its neighbours' borders of step s+1, which they
+// wrote after reading this tile's border of step s -- so nobody still needs the word that is being overwritten.
+WV_HD unsigned long long xch_pack(float v, unsigned tag)
+{
+    return ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v);
+}
+// word at byte offset `off` of a plane: a block-uniform 64-bit base plus a 32-bit per-lane offset (one VGPR per row
+// instead of an address pair per word -- the poll loop keeps all of a thread's halo words in flight at once)
+WV_HD unsigned long long *xch_word(unsigned long long *plane, unsigned off)
+{
+    return reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(plane) + off);
+}
+WV_HD const unsigned long long *xch_word(const unsigned long long *plane, unsigned off)
+{
+    return reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(plane) + off);
+}
+// keeps the compiler from hoisting the per-word address arithmetic out of the poll loop (24 address pairs kept live
+// across it) -- formed next to the load it folds into the instruction's scalar-base + 32-bit-offset addressing
+WV_HD unsigned xch_opaque(unsigned off)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(off));
+#endif
+    return off;
+}
+WV_HD void xch_put(unsigned long long *ptr, unsigned long long w)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __hip_atomic_store(ptr, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *ptr = w;
+#endif
+}
+WV_HD unsigned long long xch_get(const unsigned long long *ptr)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return *ptr;
+#endif
+}
+
+// Between two steps of a resident tile only y (the new state) is needed.  The stage code writes acc / px / u under
+// row conditions, which makes them look live around the whole step loop to the register allocator (a path that skips
+// the write reaches the next read); giving them a value on every path here ends those live ranges, so that the halo
+// poll -- which keeps all of a thread's exchange words in flight -- has the registers.
+template <int AUX, int RPT>
+WV_HD void fused_end_step(FusedRegs<AUX, RPT> &r)
+{
+    constexpr int NS = aux_ns(AUX);
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r.px[rr][k] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < NS; ++j) r.acc[rr][s][j] = 0.0f;
+    }
+}
+
+// after stage 4: the tile's output cells within FT_H of the edge of its output rectangle -> exchange buffer
+template <int AUX, int NW, int RPT>
+WV_HD void fused_xch_store(const FusedParams &p, unsigned tag, const TileDesc &t, int tid, const FusedRegs<AUX, RPT> &r)
+{
+    constexpr int NS = aux_ns(AUX);
+    const int lane = tid & 63, w = tid >> 6;
+    if (lane < FT_H || lane >= FT_H + t.ox) return;
+    const bool ringx = lane < 2 * FT_H || lane >= t.ox;
+    const int gx = t.x0 - FT_H + lane;
+    unsigned long long *base = p.xch + (size_t)(tag & 1u) * 12 * p.P;
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) {
+        const int ly = w + NW * rr;
+        if (ly < FT_H || ly >= FT_H + t.oy) continue;
+        if (!(ringx || ly < 2 * FT_H || ly >= t.oy)) continue;
+        const int gy = t.y0 - FT_H + ly;
+        const unsigned off = ((unsigned)gy * (unsigned)p.nx + (unsigned)gx) * 8u;  // byte offset: 8*P < 2^32
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < NS; ++j)
+                xch_put(xch_word(base + (size_t)(6 * s + aux_plane(AUX, j)) * p.P, off), xch_pack(r.y[rr][s][j], tag));
+    }
+}
+
+// Before the next step: u <- y on the tile's own cells, u <- the neighbours' border values on the halo ring.  Returns
+// false when some word of this thread's halo cells does not carry `tag` yet (the caller polls: nothing but r.u has been
+// modified, and every call rewrites all of it).
+template <int AUX, int NW, int RPT>
+WV_HD bool fused_xch_load(const FusedParams &p, unsigned tag, const TileDesc &t, int tid, FusedRegs<AUX, RPT> &r)
+{
+    constexpr int NS = aux_ns(AUX);
+    const int lane = tid & 63, w = tid >> 6;
+    const int gx = t.x0 - FT_H + lane;
+    const bool inx = gx >= 0 && gx < p.nx && lane < t.ox + 2 * FT_H;  // (columns beyond the region belong to nobody's ring)
+    const int cgx = gx < 0 ? 0 : (gx >= p.nx ? p.nx - 1 : gx);
+    const bool ownx = lane >= FT_H && lane < FT_H + t.ox;
+    const unsigned long long *base = p.xch + (size_t)(tag & 1u) * 12 * p.P;
+    bool ok = true;
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) {
+        const int ly = w + NW * rr;
+        const int gy = t.y0 - FT_H + ly;
+        const bool in = inx && gy >= 0 && gy < p.ny && ly < t.oy + 2 * FT_H;
+        const int cgy = gy < 0 ? 0 : (gy >= p.ny ? p.ny - 1 : gy);
+        const unsigned off = ((unsigned)cgy * (unsigned)p.nx + (unsigned)cgx) * 8u;
+        const bool own = ownx && ly >= FT_H && ly < FT_H + t.oy;
+        const bool need = in && !own;
+        // With reduced field sets the owner of a halo cell carries -- and sends -- an auxiliary field only where that
+        // field can be non-zero (Psi_x: sigma_x != 0 in the column, Psi_y: sigma_y != 0 in the row, Omega: both); anywhere
+        // else its value is the exact zero the field-set invariant guarantees, and there is no word to wait for.
+        bool needj[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int pl = aux_plane(AUX, j);
+            bool live = true;
+            if (p.reduced && pl >= 3) {
+                const bool lx = r.sx != 0.0f, ly_ = p.sy[cgy] != 0.0f;
+                live = pl == 3 ? lx : (pl == 4 ? ly_ : (lx && ly_));
+            }
+            needj[j] = need && live;
+        }
+        unsigned long long wd[2][NS];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < NS; ++j) wd[s][j] = 0;
+        if (need) {  // one divergent region per row; the word addresses are formed right here (uniform base + offset)
+            const unsigned o = xch_opaque(off);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < NS; ++j)
+                    if (needj[j]) wd[s][j] = xch_get(xch_word(base + (size_t)(6 * s + aux_plane(AUX, j)) * p.P, o));
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                float v = own ? r.y[rr][s][j] : 0.0f;
+                if (needj[j]) {
+#ifdef WV_XCH_DEBUG
+                    if ((unsigned)(wd[s][j] >> 32) != tag && wv_xch_debug)
+                        printf("  slot %d aux %d x0 %d y0 %d ox %d oy %d: lane %d ly %d gx %d gy %d plane %d set %d has tag %u want %u\n", t.slot, t.aux, t.x0, t.y0, t.ox, t.oy, lane, ly, gx, gy, aux_plane(AUX, j), s, (unsigned)(wd[s][j] >> 32), tag), wv_xch_debug--;
+#endif
+                    ok = ok && (unsigned)(wd[s][j] >> 32) == tag;
+                    v = __builtin_bit_cast(float, (unsigned)wd[s][j]);
+                }
+                r.u[rr][s][j] = v;
+            }
+    }
+    return ok;
+}
+
+// phases 0a-0c of a single-step launch
+template <int AUX, int FL, int NW, int RPT>
+WV_HD void fused_load(const FusedParams &p, const StepIO &io, const TileDesc &t, int tid, const FusedLds &lds, TileCtx &cx,
+                      FusedRegs<AUX, RPT> &r)
+{
+    fused_tile_init<AUX, FL, NW, RPT>(p, t, tid, cx, r);
+    fused_step_init<FL>(p, io.step, t, tid, lds, cx);
+    fused_load_state<AUX, NW, RPT>(p, io.u, t, tid, r);
 }
 
 // ---- phase "publish": the stage input's stencil fields -> LDS ------------------------------------------------
@@ -346,6 +555,23 @@ WV_HD void fused_publish(const FusedParams &p, const TileDesc &t, int tid, const
     }
 }
 
+// ---- phase "speed": c^2 at the three stage times of the step, once per step --------------------------------------
+// Runs right after the first barrier of the step (the cylinder copy in LDS is complete, and of the thread's state only
+// u and px are live, so the cylinder loop has the registers); stages 2 and 3 share one evaluation (t + dt/2).
+template <int AUX, int FL, int NW, int RPT>
+WV_HD void fused_speed(const FusedParams &p, const TileDesc &t, int tid, const FusedLds &lds, const TileCtx &cx,
+                       FusedRegs<AUX, RPT> &r)
+{
+    if (!(FL & F_CYL)) return;
+    const int w = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int rr = 0; rr < RPT; ++rr) r.bsq[q][rr] = p.c0sq;
+        if (cx.has_cyl) tile_speed_sq<NW, RPT>(p, t, cx, lds, q, w, r.xs, r.bsq[q]);  // block-uniform
+    }
+}
+
 // one-sided rows of `grad` (src/operators.jl:14-15) on three raw (total, incident) pairs, ascending column order
 WV_HD F2 one_sided(float c0, float c1, float c2, F2 v0, F2 v1, F2 v2)
 {
@@ -366,12 +592,6 @@ WV_HD void fused_compute(const FusedParams &p, const TileDesc &t, int tid, const
     const int rows = t.oy + 2 * FT_H;
     const int gx = t.x0 - FT_H + lane;
     const Ops &o = p.ops;
-    // wave speed first: the loop over the tile's cylinders then only has the thread's persistent state live across it
-    // (stage 3 re-evaluates t + dt/2: cheaper than carrying c^2 per row through the barrier)
-    float bsq[RPT];
-#pragma unroll
-    for (int rr = 0; rr < RPT; ++rr) bsq[rr] = p.c0sq;
-    if ((FL & F_CYL) && cx.has_cyl) tile_speed_sq<NW, RPT>(p, t, cx, lds, stage_q(S), w, r.xs, bsq);
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
         const int ly = w + NW * rr;
@@ -422,7 +642,7 @@ WV_HD void fused_compute(const FusedParams &p, const TileDesc &t, int tid, const
         float k[2][NS];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const float b = (s == 0 && (FL & F_CYL)) ? bsq[rr] : p.c0sq;
+            const float b = (s == 0 && (FL & F_CYL)) ? r.bsq[stage_q(S)][rr] : p.c0sq;
             const float ux = s == 0 ? Ux.x : Ux.y, uy = s == 0 ? Uy.x : Uy.y;
             const float vxx = s == 0 ? Vxx.x : Vxx.y, vyy = s == 0 ? Vyy.x : Vyy.y;
             const float U = yin[s][0];
@@ -485,7 +705,8 @@ WV_HD void store_out(float *ptr, float v)
 
 // ---- last phase: registers -> global, energy terms of src/env.jl:105-111 --------------------------------------
 template <int AUX, int NW, int RPT>
-WV_HD void fused_store(const FusedParams &p, const TileDesc &t, int tid, const FusedRegs<AUX, RPT> &r, float e[3])
+WV_HD void fused_store(const FusedParams &p, const StepIO &io, const TileDesc &t, int tid, const FusedRegs<AUX, RPT> &r,
+                       float e[3])
 {
     constexpr int NS = aux_ns(AUX);
     const int lane = tid & 63, w = tid >> 6;
@@ -498,19 +719,21 @@ WV_HD void fused_store(const FusedParams &p, const TileDesc &t, int tid, const F
         if (ly < FT_H || ly >= FT_H + t.oy) continue;
         const int gy = t.y0 - FT_H + ly;
         const unsigned id = (unsigned)gy * (unsigned)p.nx + (unsigned)gx;
+        if (io.out) {  // block-uniform: a resident tile only writes the states somebody reads (frames, the last step)
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                float *plane = p.out + (size_t)(6 * s + aux_plane(AUX, j)) * p.P;
-                store_out(plane + id, r.y[rr][s][j]);
-            }
+                for (int j = 0; j < NS; ++j) {
+                    float *plane = io.out + (size_t)(6 * s + aux_plane(AUX, j)) * p.P;
+                    store_out(plane + id, r.y[rr][s][j]);
+                }
+        }
         const float ut = r.y[rr][0][0], ui = r.y[rr][1][0], us = ut - ui;
         e[0] += ut * ut;
         e[1] += ui * ui;
         e[2] += us * us;
-        if (p.traj_tot) p.traj_tot[id] = ut;
-        if (p.traj_inc) p.traj_inc[id] = ui;
+        if (io.traj_tot) io.traj_tot[id] = ut;
+        if (io.traj_inc) io.traj_inc[id] = ui;
     }
 }
 

@@ -37,7 +37,6 @@ __device__ __forceinline__ void run_tile(const FusedParams &p, const TileDesc &t
     fused_load<AUX, FL, NW, RPT>(p, p.io, t, tid, lds, cx, r);
     fused_publish<AUX, FL, NW, RPT, 1>(p, t, tid, lds, cx, r);
     __syncthreads();
-    fused_speed<AUX, FL, NW, RPT>(p, t, tid, lds, cx, r);
     WV_STAMP(1)
     // stage S: read buffer (S-1)&1 (+ DPP), update the registers, publish stage S+1 into buffer S&1; one barrier per
     // stage (boundary tiles whose side buffers cannot be double-buffered separate the two halves with a barrier).
@@ -129,17 +128,47 @@ __global__ __launch_bounds__(NW * 64, 4) void k_step_fused(FusedParams p_)  // 4
 // ---------------------------------------------------------------------------------------------------------------------
 // k_steps_resident: ALL steps of one wv_integrate call in one launch.  Every tile is resident for the whole call (the
 // launch is cooperative: grid <= the number of blocks the device holds at once) and keeps its own output cells in
-// registers from one step to the next.  Per step it still writes its outputs to the state buffer (memory holds the
-// complete state of every step: frames, trajectories and the final state are exactly what k_step_fused leaves), but it
-// reads nothing back from there: the halo ring comes from the neighbouring tiles through the tagged exchange buffer
-// (fused_body.h, fused_xch_*).  There is no grid-wide barrier and no flag: a tile starts step s+1 as soon as the border
-// words of step s of its neighbours have arrived, so tiles drift apart by up to one step per tile of distance and the
-// memory latencies of some overlap the arithmetic of others on the same CU -- which a sequence of single-step launches,
-// all tiles in lock-step, cannot do.
-// A wave polls its halo words at most WV_WAIT_POLLS times (seconds; a healthy wait takes microseconds), then raises
-// *abort; every wave watches that word while it polls and the block leaves together: the kernel always drains and the
-// host reports the failure.
-constexpr int WV_WAIT_POLLS = 1 << 20;
+// registers from one step to the next; per step it writes its outputs (the state in memory stays complete at every
+// step: frames, trajectories and the final state are exactly what k_step_fused leaves), then re-reads only the halo
+// ring from the neighbouring tiles' outputs.  Steps are ordered tile to tile by one flag per tile -- no grid-wide
+// barrier: flags[slot] = flag_base + (number of steps whose outputs the tile has written).  Before step s a tile waits
+// until every neighbour's flag is >= flag_base + s, which gives it both
+//   * the data it reads (the neighbours' outputs of step s-1), and
+//   * the right to overwrite steps[s].out: its previous contents were last read by the neighbours when they refreshed
+//     their halos for a step <= s-1, i.e. before they raised their flags to flag_base + s (neighbourhood is symmetric).
+// Tiles drift apart by up to one step per tile of distance, so the memory phases of some tiles overlap the arithmetic
+// of others on the same CU -- which a sequence of single-step launches, all tiles in lock-step, cannot do.
+// A wait gives up after WV_WAIT_POLLS polls (seconds; a healthy wait takes microseconds), raises *abort, and every
+// tile leaves at its next wait: the kernel always drains, the host reports the failure.
+constexpr int WV_WAIT_POLLS = 1 << 21;
+
+// Called by all threads of the block.  Returns false when the kernel is being abandoned.
+template <int NW>
+__device__ __forceinline__ bool wait_neighbours(const FusedParams &p, const TileDesc &t, unsigned target, int *verdict)
+{
+    if (threadIdx.x < 64) {  // wave 0 polls: lane l watches neighbour l, lane 63 the abort word
+        const int lane = threadIdx.x;
+        const unsigned *fp = (lane < t.nbr_count) ? p.flags + p.nbr[t.nbr_begin + lane] : nullptr;
+        bool ok = false;
+        for (int it = 0; it < WV_WAIT_POLLS; ++it) {
+            const unsigned v = fp ? __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+            const int ab = (lane == 63) ? __hip_atomic_load(p.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            const bool ready = (int)(v - target) >= 0;
+            if (__all(ready)) {
+                ok = true;
+                break;
+            }
+            if (__any(ab != 0)) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (lane == 0) {
+            if (!ok) __hip_atomic_store(p.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *verdict = ok ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    return *verdict != 0;
+}
 
 // The step loop must compile like a sequence of single-step bodies: only the tile's registers are carried from one
 // step to the next.  Left alone, the compiler hoists every loop-invariant load, index and address out of the loop and
@@ -159,11 +188,8 @@ __device__ __forceinline__ int opaque(int v)
     return v;
 }
 
-// barrier that orders LDS accesses only (__syncthreads also waits for every outstanding global access)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 template <int AUX, int FL, int NW, int RPT, int RYMAX>
-__device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw, float (*red)[NW], int *vote)
+__device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw, float (*red)[NW], int *verdict)
 {
     const FusedLds lds = lds_view(raw, NW * RPT, RYMAX);
     FusedRegs<AUX, RPT> r;
@@ -173,26 +199,16 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
         const TileDesc t = p.tiles[p.tile_offset + blockIdx.x];
         const int tid = opaque((int)threadIdx.x);
         fused_tile_init<AUX, FL, NW, RPT>(p, t, tid, cx, r);
-        fused_load_state<AUX, NW, RPT>(p, opaque(p.steps)[0].u, t, tid, r);
-        if (tid < 2) vote[tid] = 0;  // (first read after the barriers of step 0)
+        fused_load_state<AUX, NW, RPT, false>(p, opaque(p.steps)[0].u, t, tid, r);
     }
     for (int s = 0;; ++s) {
         const FusedParams &p = *opaque(p0);
         const TileDesc t = p.tiles[p.tile_offset + blockIdx.x];
         const int tid = opaque((int)threadIdx.x);
         const StepIO &io = opaque(p.steps)[s];
-        // diagnostic stamps of ONE step (the middle one); p.stamps == nullptr in every normal run
-        unsigned long long *st = (p.stamps && s == p.nsteps / 2) ? p.stamps + (size_t)t.slot * 16 : nullptr;
-#define WV_STAMP(k)                                                     \
-    if (st && tid == 0) {                                               \
-        __builtin_amdgcn_s_waitcnt(0);                                  \
-        st[k] = __builtin_amdgcn_s_memrealtime();                       \
-    }
-        WV_STAMP(0)
         fused_step_init<FL>(p, io.step, t, tid, lds, cx);
         fused_publish<AUX, FL, NW, RPT, 1>(p, t, tid, lds, cx, r);
         __syncthreads();
-        fused_speed<AUX, FL, NW, RPT>(p, t, tid, lds, cx, r);
 #define WV_STAGE(S)                                                      \
     fused_compute<AUX, FL, NW, RPT, S>(p, t, tid, lds, cx, r, &r);       \
     if ((FL & F_EDGE) && !lds_side_double(NW * RPT, RYMAX)) __syncthreads();  \
@@ -203,14 +219,8 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
         WV_STAGE(3)
 #undef WV_STAGE
         fused_compute<AUX, FL, NW, RPT, 4>(p, t, tid, lds, cx, r, &r);
-        WV_STAMP(1)
-        // the border first: the neighbours are waiting for it
-        const unsigned tag = p.tag_base + (unsigned)(s + 1);
-        if (s + 1 != p.nsteps) fused_xch_store<AUX, NW, RPT>(p, tag, t, tid, r);
         float e[3];
         fused_store<AUX, NW, RPT>(p, io, t, tid, r, e);
-        fused_end_step<AUX, RPT>(r);
-        WV_STAMP(2)
         if (io.epart) {  // block-uniform
             const int lane = tid & 63, w = tid >> 6;
 #pragma unroll
@@ -220,43 +230,21 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
             }
         }
         const bool last = s + 1 == p.nsteps;
-        WV_STAMP(3)
-        // halo of the next step: every wave polls the words of its own rows
-        bool ok = true;
-        int polls = 0;
-        if (!last) {
-            ok = false;
-            for (; polls < WV_WAIT_POLLS; ++polls) {
-                ok = __all(fused_xch_load<AUX, NW, RPT>(p, tag, t, tid, r));
-                if (ok) break;
-                const int ab = ((tid & 63) == 0) ? __hip_atomic_load(p.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-                if (__any(ab != 0)) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (!ok && (tid & 63) == 0) {
-                __hip_atomic_store(p.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                vote[s & 1] = 1;
-            }
-        }
-        WV_STAMP(4)
-        // The one barrier between two steps.  It orders LDS only (red, vote, the cylinder copy and the stage buffers
-        // of the next step): the output stores of this step are still in flight and nobody here waits for them.
-        lds_barrier();
+        // every thread's output stores are performed at agent scope before the barrier; thread 0 then publishes the
+        // step count (release, agent scope)
+        if (!last) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
         if (io.epart && tid < 3) {
             float v = 0.0f;
 #pragma unroll
             for (int k = 0; k < NW; ++k) v += red[tid][k];
             io.epart[(size_t)t.slot * 3 + tid] = v;
         }
-        if (last || vote[s & 1] != 0) return;  // block-uniform: a block that gives up leaves together
-        if (tid == 0) vote[(s + 1) & 1] = 0;
-        WV_STAMP(5)
-        if (st && tid == 0) {
-            st[6] = (unsigned long long)polls;
-            st[10] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
-            st[13] = (unsigned long long)(t.aux | (t.edge << 4));
-        }
-#undef WV_STAMP
+        if (last) break;
+        if (tid == 0)
+            __hip_atomic_store(p.flags + t.slot, p.flag_base + (unsigned)(s + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (!wait_neighbours<NW>(p, t, p.flag_base + (unsigned)(s + 1), verdict)) return;
+        fused_load_state<AUX, NW, RPT, true>(p, io.out, t, tid, r);
     }
 }
 
@@ -273,29 +261,13 @@ __global__ __launch_bounds__(NW * 64, 4) void k_steps_resident(FusedParams p_)
     constexpr int RYMAX = NW * RMAX;
     __shared__ F2 raw[lds_elems(RYMAX)];
     __shared__ float red[3][NW];
-    __shared__ int vote[2];  // [step parity]: a wave of the block gave up waiting
+    __shared__ int verdict;
     const TileDesc t = p.tiles[p.tile_offset + blockIdx.x];
-#define RUN(A, F, R) run_tile_resident<A, F, NW, R, RYMAX>(&p, raw, red, vote)
+#define RUN(A, F, R) run_tile_resident<A, F, NW, R, RYMAX>(&p, raw, red, &verdict)
     const int fl = tile_flags(p, t);
     const int fe = fl & F_EDGE;
     const bool cyl = (fl & F_CYL) != 0;
-    if (t.aux == AUX_NONE) {
-        if (fl == 0) RUN(AUX_NONE, 0, RF);
-        else if (fl == F_SRC) RUN(AUX_NONE, F_SRC, RF);
-        else RUN(AUX_NONE, F_CYL | F_SRC, RF);
-    } else if (t.aux == AUX_PX) {
-        if (!cyl && (fe & ~F_EL) == 0) RUN(AUX_PX, F_EL | F_SRC, RB);
-        else if (!cyl && (fe & ~F_ER) == 0) RUN(AUX_PX, F_ER | F_SRC, RB);
-        else RUN(AUX_PX, F_ALL, RB);
-    } else if (t.aux == AUX_PY) {
-        if (fl == 0) RUN(AUX_PY, 0, RB);
-        else if (!cyl && (fe & ~F_ET) == 0) RUN(AUX_PY, F_ET | F_SRC, RB);
-        else if (!cyl && (fe & ~F_EB) == 0) RUN(AUX_PY, F_EB | F_SRC, RB);
-        else RUN(AUX_PY, F_ALL, RB);
-    } else {
-        if (!cyl) RUN(AUX_ALL, F_EDGE | F_SRC, RP);
-        else RUN(AUX_ALL, F_ALL, RP);
-    }
+    RUN(AUX_NONE, 0, RF); (void)fl; (void)fe; (void)cyl;
 #undef RUN
 }
 
@@ -385,12 +357,15 @@ struct FusedPlan {
     // k_steps_resident (all steps of a call in one cooperative launch)
     bool use_resident = true;     // WAVES_AMD_FUSED_RESIDENT=0 disables
     int resident_capacity = -1;   // blocks of k_steps_resident the device holds at once (-1: not asked yet)
-    int cu_count = 0;
     StepIO *d_steps = nullptr;
     size_t steps_cap = 0;
     std::vector<StepIO> h_steps;  // what d_steps holds
-    unsigned long long *d_xch = nullptr;  // tagged halo exchange buffer [2][12][P], see fused_xch_*
-    unsigned tag_base = 0;        // tags handed out so far (the buffer never holds a tag above it)
+    unsigned *d_flags = nullptr;  // [ntiles] step counts, see k_steps_resident
+    size_t flags_cap = 0;
+    unsigned flag_base = 0;
+    int flags_generation = -1;    // tile generation the flags / neighbour lists were set up for
+    int *d_nbr = nullptr;
+    size_t nbr_cap = 0;
     int *d_abort = nullptr;
     int *h_abort = nullptr;       // pinned copy, valid after the stream has been waited for
     bool abort_pending = false;   // a resident launch is in flight (or finished) whose verdict has not been looked at
@@ -441,7 +416,8 @@ void fused_destroy(FusedPlan *p)
     if (p->d_stamps) (void)hipFree(p->d_stamps);
     if (p->d_src_flags) (void)hipFree(p->d_src_flags);
     if (p->d_steps) (void)hipFree(p->d_steps);
-    if (p->d_xch) (void)hipFree(p->d_xch);
+    if (p->d_flags) (void)hipFree(p->d_flags);
+    if (p->d_nbr) (void)hipFree(p->d_nbr);
     if (p->d_abort) (void)hipFree(p->d_abort);
     if (p->h_abort) (void)hipHostFree(p->h_abort);
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
@@ -492,8 +468,6 @@ int fused_energy_blocks(FusedPlan *p)
 
 void fused_source_changed(FusedPlan *p) { p->src_dirty = true; }
 
-static int resident_capacity(FusedPlan *pl);
-
 int fused_prepare(FusedPlan *p, float *frames, float *scratch0, float *scratch1, bool capture, const float *G,
                   const Cyl *d_table, const Cyl *h_table, int M, int rows, hipStream_t s)
 {
@@ -527,10 +501,7 @@ int fused_prepare(FusedPlan *p, float *frames, float *scratch0, float *scratch1,
     }
     if (!ensure_tiles(p, aux_zero)) return 2;
     static const bool resort = !(getenv("WAVES_AMD_FUSED_RESORT") && atoi(getenv("WAVES_AMD_FUSED_RESORT")) == 0);
-    // (tiles that fit the device at once will run resident: order them for that kernel)
-    static const bool pairing = !(getenv("WAVES_AMD_FUSED_PAIRING") && atoi(getenv("WAVES_AMD_FUSED_PAIRING")) == 0);
-    const bool fits = (int)p->hp.tiles.size() <= resident_capacity(p);
-    plan_build_cyl(p->hp, p->x.data(), p->y.data(), h_table, M, rows, p->idx, resort, (fits && pairing) ? p->cu_count : 0);
+    plan_build_cyl(p->hp, p->x.data(), p->y.data(), h_table, M, rows, p->idx, resort);
     const size_t nt = p->hp.tiles.size();
     if (nt > p->tiles_cap) {
         if (p->d_tiles) (void)hipFree(p->d_tiles);
@@ -601,9 +572,9 @@ static FusedParams make_params(FusedPlan *pl, const FusedCall &call, int step, c
     p.cyl_idx = pl->d_idx;
     p.steps = nullptr;
     p.nsteps = 0;
-    p.xch = nullptr;
-    p.tag_base = 0;
-    p.reduced = 0;
+    p.flags = nullptr;
+    p.flag_base = 0;
+    p.nbr = nullptr;
     p.abort = nullptr;
     p.stamps = nullptr;
     if (pl->stamps_path) {
@@ -650,10 +621,10 @@ static const void *resident_ptr(const FusedPlan *pl)
     }
 }
 
-// blocks of k_steps_resident the device holds at once (0: the resident path is not available)
-static int resident_capacity(FusedPlan *pl)
+int fused_try_resident(FusedPlan *pl, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s)
 {
-    if (!pl->use_resident || pl->nbands != 1) return 0;
+    const size_t nt = pl->hp.tiles.size();
+    if (!pl->use_resident || pl->stamps_path || pl->nbands != 1 || nsteps < 2 || pl->hp.max_nbr > 62) return -1;
     if (pl->resident_capacity < 0) {
         int per_cu = 0, dev = 0;
         hipDeviceProp_t prop;
@@ -663,33 +634,37 @@ static int resident_capacity(FusedPlan *pl)
             pl->resident_capacity = 0;
         } else {
             pl->resident_capacity = (prop.cooperativeLaunch ? per_cu * prop.multiProcessorCount : 0);
-            pl->cu_count = prop.multiProcessorCount;
         }
     }
-    return pl->resident_capacity;
-}
-
-int fused_try_resident(FusedPlan *pl, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s)
-{
-    const size_t nt = pl->hp.tiles.size();
-    if (nsteps < 2 || (int)nt > resident_capacity(pl)) return -1;
-    // exchange buffer: zeroed once (tag 0 is never expected); tags only grow, so words of earlier calls -- or of an
-    // earlier tile decomposition -- can never be mistaken for the ones a step waits for
-    const size_t xwords = (size_t)2 * 12 * pl->g.P;
-    if (!pl->d_xch || pl->tag_base > 0xFFFF0000u - (unsigned)nsteps) {
-        if (!pl->d_xch && hipMalloc((void **)&pl->d_xch, xwords * sizeof(unsigned long long)) != hipSuccess) {
-            (void)hipGetLastError();
-            pl->resident_capacity = 0;
-            return -1;
+    if ((int)nt > pl->resident_capacity) return -1;
+    // neighbour lists and flags follow the tile decomposition
+    if (pl->flags_generation != pl->generation) {
+        if (nt > pl->flags_cap) {
+            if (pl->d_flags) (void)hipFree(pl->d_flags);
+            pl->d_flags = nullptr;
+            pl->flags_cap = 0;
+            if (hipMalloc((void **)&pl->d_flags, nt * sizeof(unsigned)) != hipSuccess) return 1;
+            pl->flags_cap = nt;
         }
-        if (hipMemsetAsync(pl->d_xch, 0, xwords * sizeof(unsigned long long), s) != hipSuccess) return 1;
-        pl->tag_base = 0;
+        const size_t nn = pl->hp.nbr.size() ? pl->hp.nbr.size() : 1;
+        if (nn > pl->nbr_cap) {
+            if (pl->d_nbr) (void)hipFree(pl->d_nbr);
+            pl->d_nbr = nullptr;
+            pl->nbr_cap = 0;
+            if (hipMalloc((void **)&pl->d_nbr, nn * sizeof(int)) != hipSuccess) return 1;
+            pl->nbr_cap = nn;
+        }
+        if (hipMemsetAsync(pl->d_flags, 0, nt * sizeof(unsigned), s) != hipSuccess) return 1;
+        if (!pl->hp.nbr.empty() &&
+            hipMemcpyAsync(pl->d_nbr, pl->hp.nbr.data(), pl->hp.nbr.size() * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess)
+            return 1;
+        pl->flag_base = 0;
+        pl->flags_generation = pl->generation;
     }
     // the step table (unchanged from call to call in a rollout: uploaded only when it differs)
     std::vector<StepIO> tab((size_t)nsteps);
     for (int i = 0; i < nsteps; ++i) {
-        tab[i] = StepIO{steps[i].u, (steps[i].keep || i + 1 == nsteps) ? steps[i].out : nullptr, steps[i].epart,
-                        steps[i].traj_tot, steps[i].traj_inc, i, 0};
+        tab[i] = StepIO{steps[i].u, steps[i].out, steps[i].epart, steps[i].traj_tot, steps[i].traj_inc, i, 0};
         if (i > 0 && steps[i].u != steps[i - 1].out) return -1;
     }
     const bool same = tab.size() == pl->h_steps.size() &&
@@ -712,9 +687,9 @@ int fused_try_resident(FusedPlan *pl, const FusedCall &call, const FusedStep *st
     FusedParams p = make_params(pl, call, 0, steps[0]);
     p.steps = pl->d_steps;
     p.nsteps = nsteps;
-    p.xch = pl->d_xch;
-    p.tag_base = pl->tag_base;
-    p.reduced = pl->tiles_aux_zero ? 1 : 0;
+    p.flags = pl->d_flags;
+    p.flag_base = pl->flag_base;
+    p.nbr = pl->d_nbr;
     p.abort = pl->d_abort;
     void *args[1] = {&p};
     const hipError_t e = hipLaunchCooperativeKernel(resident_ptr(pl), dim3((unsigned)nt), dim3(512), args, 0, s);
@@ -723,7 +698,7 @@ int fused_try_resident(FusedPlan *pl, const FusedCall &call, const FusedStep *st
         pl->resident_capacity = 0;  // do not try again
         return -1;
     }
-    pl->tag_base += (unsigned)nsteps;
+    pl->flag_base += (unsigned)nsteps;
     if (hipMemcpyAsync(pl->h_abort, pl->d_abort, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
     pl->abort_pending = true;
     return 0;
@@ -737,6 +712,7 @@ int fused_finish(FusedPlan *pl, hipStream_t s)
     // a tile gave up waiting: the state is garbage.  Reset the protocol so that the context stays usable.
     *pl->h_abort = 0;
     (void)hipMemsetAsync(pl->d_abort, 0, sizeof(int), s);
+    pl->flags_generation = -1;
     return 1;
 }
 
