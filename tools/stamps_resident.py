@@ -34,3 +34,11 @@ for i in order[:12]:
 print("wait percentiles ns:", np.percentile(d[:, 3], [0, 10, 50, 90, 100]).round())
 print("compute percentiles ns:", np.percentile(d[:, 0], [0, 10, 50, 90, 100]).round())
 print("refresh percentiles ns:", np.percentile(d[:, 4], [0, 10, 50, 90, 100]).round())
+
+X = a[:, 8:8 + 12].astype(np.float64) * 10.0
+cyl = a[:, 7]
+print("inside the step (ns): init+pub1+barrier | speed | stage1 | stages2-3 | stage4, by tile class")
+for nm, m in (("NONE cyl=0", (aux == 0) & (cyl == 0)), ("NONE cyl>0", (aux == 0) & (cyl > 0)), ("PX", aux == 1), ("PY", aux == 2), ("ALL", aux == 3)):
+    if m.any():
+        print(f"  {nm:11s} n={m.sum():3d} {np.mean(X[m,7]-X[m,0]):6.0f} | {np.mean(X[m,8]-X[m,7]):6.0f} | {np.mean(X[m,9]-X[m,8]):6.0f} | "
+              f"{np.mean(X[m,11]-X[m,9]):6.0f} | {np.mean(X[m,1]-X[m,11]):6.0f}")

@@ -155,6 +155,7 @@ struct FusedRegs {
     float sx;               // sigma_x of the column
     float xs;               // x coordinate of the column (tiles with cylinders only)
     float bsq[3][RPT];      // c^2 of the total set at the three stage times of the step (variants with F_CYL only)
+    int cidx;               // threads 0 .. 3*cyl_count-1 stage the tile's cylinders in LDS: table column of this one
 };
 
 WV_HD int stage_q(int S) { return S == 1 ? 0 : (S == 4 ? 2 : 1); }  // which of the three stage times a stage uses
@@ -197,43 +198,49 @@ WV_HD void speed_accum(const Cyl c, float x, float y, int &count, float &cd)
     cd = cd + (in ? c.c : 0.0f);
 }
 
-// c^2 of the total set for the RPT rows of one thread at stage time q.  The loop over the tile's cylinders is the
-// OUTER loop (one broadcast LDS read per cylinder and stage instead of one per row); each row still accumulates its
-// cylinders in ascending order, exactly like sum(mask .* c, dims = 3).
+// c^2 of the total set for the RPT rows of one thread at the three stage times of a step.  The loop over the tile's
+// cylinders is the OUTER loop and handles the three stage times together (three broadcast LDS reads in flight per
+// iteration instead of one per row and time); each (time, row) still accumulates its cylinders in ascending order,
+// exactly like sum(mask .* c, dims = 3).
 template <int NW, int RPT>
-WV_HD void tile_speed_sq(const FusedParams &p, const TileDesc &t, const TileCtx &cx, const FusedLds &lds, int q, int w,
-                         float x, float bsq[RPT])
+WV_HD void tile_speed_sq(const FusedParams &p, const TileDesc &t, const TileCtx &cx, const FusedLds &lds, int w, float x,
+                         float bsq[3][RPT])
 {
-    int count[RPT];
-    float cd[RPT], ys[RPT];
+    int count[3][RPT];
+    float cd[3][RPT], ys[RPT];
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
         const int gy = t.y0 - FT_H + w + NW * rr;
         ys[rr] = p.y[gy < 0 ? 0 : (gy >= p.ny ? p.ny - 1 : gy)];
-        count[rr] = 0;
-        cd[rr] = 0.0f;
-    }
-    if (cx.cyl_lds) {
-        const Cyl *row = lds.cyl + q * t.cyl_count;
-        for (int k = 0; k < t.cyl_count; ++k) {
-            const Cyl c = row[k];
 #pragma unroll
-            for (int rr = 0; rr < RPT; ++rr) speed_accum(c, x, ys[rr], count[rr], cd[rr]);
-        }
-    } else {
-        const Cyl *row = p.cyl_tab + (size_t)(3 * cx.step + q) * p.M;
-        const int n = t.cyl_count < 0 ? p.M : t.cyl_count;
-        for (int k = 0; k < n; ++k) {
-            const Cyl c = row[t.cyl_count < 0 ? k : p.cyl_idx[t.cyl_begin + k]];
-#pragma unroll
-            for (int rr = 0; rr < RPT; ++rr) speed_accum(c, x, ys[rr], count[rr], cd[rr]);
+        for (int q = 0; q < 3; ++q) {
+            count[q][rr] = 0;
+            cd[q][rr] = 0.0f;
         }
     }
+    const int n = t.cyl_count < 0 ? p.M : t.cyl_count;
+    for (int k = 0; k < n; ++k) {
+        Cyl c[3];
+        if (cx.cyl_lds) {
 #pragma unroll
-    for (int rr = 0; rr < RPT; ++rr) {
-        const float c = (count[rr] == 0 ? p.c0 : 0.0f) + cd[rr];  // C(t)   src/env.jl:99, src/designs.jl:110-116
-        bsq[rr] = c * c;                                           // c .^ 2 src/dynamics.jl:159
+            for (int q = 0; q < 3; ++q) c[q] = lds.cyl[q * t.cyl_count + k];
+        } else {
+            const int col = t.cyl_count < 0 ? k : p.cyl_idx[t.cyl_begin + k];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) c[q] = p.cyl_tab[(size_t)(3 * cx.step + q) * p.M + col];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int rr = 0; rr < RPT; ++rr) speed_accum(c[q], x, ys[rr], count[q][rr], cd[q][rr]);
     }
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int rr = 0; rr < RPT; ++rr) {
+            const float c = (count[q][rr] == 0 ? p.c0 : 0.0f) + cd[q][rr];  // C(t)   src/env.jl:99, src/designs.jl:110-116
+            bsq[q][rr] = c * c;                                                // c .^ 2 src/dynamics.jl:159
+        }
 }
 
 // Value of `v` in the lane to the left / right of this one (the cell at x-1 / x+1 of the same row).  On the device `nb`
@@ -282,6 +289,7 @@ WV_HD void fused_tile_init(const FusedParams &p, const TileDesc &t, int tid, Til
     cx.cyl_lds = cx.has_cyl && t.cyl_count > 0 && t.cyl_count <= FT_MAXCYL;
     r.sx = (AUX == AUX_PX || AUX == AUX_ALL) ? p.sx[cgx] : 0.0f;
     r.xs = ((FL & F_CYL) && cx.has_cyl) ? p.x[cgx] : 0.0f;
+    r.cidx = ((FL & F_CYL) && cx.cyl_lds && tid < 3 * t.cyl_count) ? p.cyl_idx[t.cyl_begin + tid % t.cyl_count] : 0;
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
         const int ly = w + NW * rr;
@@ -294,16 +302,30 @@ WV_HD void fused_tile_init(const FusedParams &p, const TileDesc &t, int tid, Til
 }
 
 // ---- phase 0b: the per-step scalars -----------------------------------------------------------------------------
-// (the cylinder copy in LDS is first read after the first barrier of stage 1 and last read in stage 4: the caller has a
-// barrier between stage 4 of one step and this phase of the next)
+// The tile's culled cylinders at the three stage times of a step go to LDS (threads 0 .. 3*cyl_count-1, one cylinder
+// each), in two halves so that a resident tile can have the global load of the NEXT step's cylinders in flight while it
+// waits for its halo: fused_cyl_fetch (global -> register) ... fused_cyl_commit (register -> LDS).  The LDS copy is
+// read by fused_speed only, right after the first barrier of a step; the commit for the next step may therefore happen
+// any time after that barrier and needs one barrier before the next fused_speed.
+template <int AUX, int FL, int RPT>
+WV_HD Cyl fused_cyl_fetch(const FusedParams &p, int step, const TileDesc &t, int tid, const TileCtx &cx,
+                          const FusedRegs<AUX, RPT> &r)
+{
+    if ((FL & F_CYL) && cx.cyl_lds && tid < 3 * t.cyl_count)  // block-uniform up to the thread test
+        return p.cyl_tab[(size_t)(3 * step + tid / t.cyl_count) * p.M + r.cidx];
+    return Cyl{0.0f, 0.0f, 0.0f, 0.0f};
+}
 template <int FL>
-WV_HD void fused_step_init(const FusedParams &p, int step, const TileDesc &t, int tid, const FusedLds &lds, TileCtx &cx)
+WV_HD void fused_cyl_commit(const TileDesc &t, int tid, const FusedLds &lds, const TileCtx &cx, const Cyl &c)
+{
+    if ((FL & F_CYL) && cx.cyl_lds && tid < 3 * t.cyl_count) lds.cyl[tid] = c;
+}
+template <int FL>
+WV_HD void fused_step_init(const FusedParams &p, int step, TileCtx &cx)
 {
     cx.step = step;
 #pragma unroll
     for (int q = 0; q < 3; ++q) cx.sf[q] = (cx.has_src && p.sfac_tab) ? p.sfac_tab[3 * step + q] : 0.0f;
-    if ((FL & F_CYL) && cx.cyl_lds && tid < 3 * t.cyl_count)  // block-uniform up to the thread test
-        lds.cyl[tid] = p.cyl_tab[(size_t)(3 * step + tid / t.cyl_count) * p.M + p.cyl_idx[t.cyl_begin + tid % t.cyl_count]];
 }
 
 // ---- phase 0c: global -> registers --------------------------------------------------------------------------------
@@ -340,9 +362,22 @@ WV_HD void fused_load_state(const FusedParams &p, const float *u, const TileDesc
 // -- no flag, no acknowledgement to wait for, no ordering between different words needed.  One buffer per tag parity:
 // a tile can only write the border of step s+2 after it has read its neighbours' borders of step s+1, which they
 // wrote after reading this tile's border of step s -- so nobody still needs the word that is being overwritten.
+// (On the device the value crosses into / out of the 64-bit word through an explicit register copy: otherwise the
+// register coalescer makes the long-lived state value a sub-register of the word's aligned register pair -- 24 state
+// values then occupy 24 PAIRS for the whole step, and the kernel spills.)
+WV_HD unsigned xch_copy(unsigned v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned o;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(o) : "v"(v));
+    return o;
+#else
+    return v;
+#endif
+}
 WV_HD unsigned long long xch_pack(float v, unsigned tag)
 {
-    return ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v);
+    return ((unsigned long long)tag << 32) | (unsigned long long)xch_copy(__builtin_bit_cast(unsigned, v));
 }
 // word at byte offset `off` of a plane: a block-uniform 64-bit base plus a 32-bit per-lane offset (one VGPR per row
 // instead of an address pair per word -- the poll loop keeps all of a thread's halo words in flight at once)
@@ -484,8 +519,10 @@ WV_HD bool fused_xch_load(const FusedParams &p, unsigned tag, const TileDesc &t,
                     if ((unsigned)(wd[s][j] >> 32) != tag && wv_xch_debug)
                         printf("  slot %d aux %d x0 %d y0 %d ox %d oy %d: lane %d ly %d gx %d gy %d plane %d set %d has tag %u want %u\n", t.slot, t.aux, t.x0, t.y0, t.ox, t.oy, lane, ly, gx, gy, aux_plane(AUX, j), s, (unsigned)(wd[s][j] >> 32), tag), wv_xch_debug--;
 #endif
+#ifndef WV_XCH_NOWAIT  // (timing experiment only: results are wrong without the check)
                     ok = ok && (unsigned)(wd[s][j] >> 32) == tag;
-                    v = __builtin_bit_cast(float, (unsigned)wd[s][j]);
+#endif
+                    v = __builtin_bit_cast(float, xch_copy((unsigned)wd[s][j]));
                 }
                 r.u[rr][s][j] = v;
             }
@@ -499,7 +536,8 @@ WV_HD void fused_load(const FusedParams &p, const StepIO &io, const TileDesc &t,
                       FusedRegs<AUX, RPT> &r)
 {
     fused_tile_init<AUX, FL, NW, RPT>(p, t, tid, cx, r);
-    fused_step_init<FL>(p, io.step, t, tid, lds, cx);
+    fused_step_init<FL>(p, io.step, cx);
+    fused_cyl_commit<FL>(t, tid, lds, cx, fused_cyl_fetch<AUX, FL, RPT>(p, io.step, t, tid, cx, r));
     fused_load_state<AUX, NW, RPT>(p, io.u, t, tid, r);
 }
 
@@ -565,11 +603,10 @@ WV_HD void fused_speed(const FusedParams &p, const TileDesc &t, int tid, const F
     if (!(FL & F_CYL)) return;
     const int w = tid >> 6;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < 3; ++q)
 #pragma unroll
         for (int rr = 0; rr < RPT; ++rr) r.bsq[q][rr] = p.c0sq;
-        if (cx.has_cyl) tile_speed_sq<NW, RPT>(p, t, cx, lds, q, w, r.xs, r.bsq[q]);  // block-uniform
-    }
+    if (cx.has_cyl) tile_speed_sq<NW, RPT>(p, t, cx, lds, w, r.xs, r.bsq);  // block-uniform
 }
 
 // one-sided rows of `grad` (src/operators.jl:14-15) on three raw (total, incident) pairs, ascending column order

@@ -173,8 +173,9 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
         const TileDesc t = p.tiles[p.tile_offset + blockIdx.x];
         const int tid = opaque((int)threadIdx.x);
         fused_tile_init<AUX, FL, NW, RPT>(p, t, tid, cx, r);
+        fused_cyl_commit<FL>(t, tid, lds, cx, fused_cyl_fetch<AUX, FL, RPT>(p, 0, t, tid, cx, r));  // steps[s].step == s
         fused_load_state<AUX, NW, RPT>(p, opaque(p.steps)[0].u, t, tid, r);
-        if (tid < 2) vote[tid] = 0;  // (first read after the barriers of step 0)
+        if (tid == 0) *vote = 0;  // (set by a wave that gives up; read after the first barrier of a step)
     }
     for (int s = 0;; ++s) {
         const FusedParams &p = *opaque(p0);
@@ -189,18 +190,36 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
         st[k] = __builtin_amdgcn_s_memrealtime();                       \
     }
         WV_STAMP(0)
-        fused_step_init<FL>(p, io.step, t, tid, lds, cx);
+        fused_step_init<FL>(p, io.step, cx);
         fused_publish<AUX, FL, NW, RPT, 1>(p, t, tid, lds, cx, r);
         __syncthreads();
+        WV_STAMP(7)
+        // This barrier is also the one that closes the previous step: its energy terms are complete in `red`, and a
+        // wave that gave up waiting for its halo has said so.  (There is no barrier of its own between two steps: a wave
+        // whose halo has arrived starts publishing while the others still poll -- stage buffer 0 was last read in stage
+        // 3 -- and the cylinder copy in LDS was last read right after this barrier of the previous step.)
+        if (s > 0) {
+            float *ep = opaque(p.steps)[s - 1].epart;
+            if (ep && tid < 3) {
+                float v = 0.0f;
+#pragma unroll
+                for (int k = 0; k < NW; ++k) v += red[tid][k];
+                ep[(size_t)t.slot * 3 + tid] = v;
+            }
+            if (*vote != 0) return;  // block-uniform: a block that gives up leaves together
+        }
         fused_speed<AUX, FL, NW, RPT>(p, t, tid, lds, cx, r);
+        WV_STAMP(8)
 #define WV_STAGE(S)                                                      \
     fused_compute<AUX, FL, NW, RPT, S>(p, t, tid, lds, cx, r, &r);       \
     if ((FL & F_EDGE) && !lds_side_double(NW * RPT, RYMAX)) __syncthreads();  \
     fused_publish<AUX, FL, NW, RPT, S + 1>(p, t, tid, lds, cx, r);       \
     __syncthreads();
         WV_STAGE(1)
+        WV_STAMP(9)
         WV_STAGE(2)
         WV_STAGE(3)
+        WV_STAMP(11)
 #undef WV_STAGE
         fused_compute<AUX, FL, NW, RPT, 4>(p, t, tid, lds, cx, r, &r);
         WV_STAMP(1)
@@ -219,39 +238,40 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
                 if (lane == 0) red[c][w] = v;
             }
         }
-        const bool last = s + 1 == p.nsteps;
         WV_STAMP(3)
-        // halo of the next step: every wave polls the words of its own rows
-        bool ok = true;
-        int polls = 0;
-        if (!last) {
-            ok = false;
-            for (; polls < WV_WAIT_POLLS; ++polls) {
-                ok = __all(fused_xch_load<AUX, NW, RPT>(p, tag, t, tid, r));
-                if (ok) break;
-                const int ab = ((tid & 63) == 0) ? __hip_atomic_load(p.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-                if (__any(ab != 0)) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (!ok && (tid & 63) == 0) {
-                __hip_atomic_store(p.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                vote[s & 1] = 1;
-            }
-        }
-        WV_STAMP(4)
-        // The one barrier between two steps.  It orders LDS only (red, vote, the cylinder copy and the stage buffers
-        // of the next step): the output stores of this step are still in flight and nobody here waits for them.
-        lds_barrier();
-        if (io.epart && tid < 3) {
-            float v = 0.0f;
+        if (s + 1 == p.nsteps) {  // the last step closes itself
+            lds_barrier();
+            if (io.epart && tid < 3) {
+                float v = 0.0f;
 #pragma unroll
-            for (int k = 0; k < NW; ++k) v += red[tid][k];
-            io.epart[(size_t)t.slot * 3 + tid] = v;
+                for (int k = 0; k < NW; ++k) v += red[tid][k];
+                io.epart[(size_t)t.slot * 3 + tid] = v;
+            }
+            return;
         }
-        if (last || vote[s & 1] != 0) return;  // block-uniform: a block that gives up leaves together
-        if (tid == 0) vote[(s + 1) & 1] = 0;
-        WV_STAMP(5)
+        // halo of the next step: every wave polls the words of its own rows
+        // (the next step's cylinders travel while the halo is awaited)
+        const Cyl nc = fused_cyl_fetch<AUX, FL, RPT>(p, io.step + 1, t, tid, cx, r);
+        bool ok = false;
+        int polls = 0;
+        for (; polls < WV_WAIT_POLLS; ++polls) {
+            ok = __all(fused_xch_load<AUX, NW, RPT>(p, tag, t, tid, r));
+            if (ok) break;
+            const int ab = ((tid & 63) == 0) ? __hip_atomic_load(p.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            if (__any(ab != 0)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok && (tid & 63) == 0) {
+            __hip_atomic_store(p.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *vote = 1;
+        }
+        fused_cyl_commit<FL>(t, tid, lds, cx, nc);
+        // (nothing of the next step is scheduled into the poll: it would stretch the live ranges of the exchange words
+        // over the publish phase and spill)
+        asm volatile("s_nop 0" ::: "memory");
+        WV_STAMP(4)
         if (st && tid == 0) {
+            st[5] = st[4];
             st[6] = (unsigned long long)polls;
             st[10] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
             st[13] = (unsigned long long)(t.aux | (t.edge << 4));
@@ -273,7 +293,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_steps_resident(FusedParams p_)
     constexpr int RYMAX = NW * RMAX;
     __shared__ F2 raw[lds_elems(RYMAX)];
     __shared__ float red[3][NW];
-    __shared__ int vote[2];  // [step parity]: a wave of the block gave up waiting
+    __shared__ int vote[1];  // a wave of the block gave up waiting for its halo
     const TileDesc t = p.tiles[p.tile_offset + blockIdx.x];
 #define RUN(A, F, R) run_tile_resident<A, F, NW, R, RYMAX>(&p, raw, red, vote)
     const int fl = tile_flags(p, t);
