@@ -337,3 +337,59 @@ def test_recycled_device_memory_does_not_leak_into_results():
     st, _, _ = oracle_integrate(dim, wo.to_abi(u0), ts, pml=(1.0, 0.0))
     assert np.array_equal(wo.to_abi(ctx.get_state()), st)
     ctx.close()
+
+
+# ---- the resident kernel (all steps of a call in one cooperative launch, tagged halo exchange) ------------------------
+def _run_resident_case(monkeypatch, resident, n, steps, *, capture, fields, aux, seed):
+    monkeypatch.setenv("WAVES_AMD_FUSED_RESIDENT", "1" if resident else "0")
+    rng = np.random.default_rng(seed)
+    dim, ctx = make_ctx(n, "fused")
+    grid = wo.build_grid(dim)
+    d0, d1 = small_moving_design(rng, 5, spread=4.0)
+    G = wo.build_normal(grid, np.array([[-2.0, 1.5]]), np.array([0.5]), np.array([1.0]))
+    u0 = random_state(rng, n, n, scale=0.1, aux=aux)
+    ts = wo.build_tspan(f32(0.001), 1e-5, steps)
+    ctx.set_source_shape(G, 1000.0)
+    set_design(ctx, d0, d1, ts[0], ts[-1])
+    ctx.set_state(u0)
+    sig, ut, ui = ctx.integrate(ts, capture_frames=capture, want_fields=fields)
+    tim = ctx.timing()
+    # a second action on top of the first: the exchange tags keep growing, the energy row is carried over
+    ts2 = wo.build_tspan(ts[-1], 1e-5, steps)
+    set_design(ctx, d1, d0, ts2[0], ts2[-1])
+    sig2, _, _ = ctx.integrate(ts2, capture_frames=capture)
+    out = dict(sig=sig, sig2=sig2, ut=ut, ui=ui, frames=ctx.get_frames(), state=ctx.get_state(), resident=tim["resident"],
+               launches=None)
+    ctx.close()
+    return out, (dim, u0, ts, G, d0, d1)
+
+
+@pytest.mark.parametrize("n,steps,capture,fields,aux", [(200, 30, True, False, True), (160, 21, True, True, False),
+                                                         (96, 2, False, True, False), (330, 25, True, False, False)])
+def test_resident_kernel_equals_single_step_kernels_and_oracle(monkeypatch, n, steps, capture, fields, aux):
+    """Same inputs through k_steps_resident (one launch, state in registers, tagged halo exchange) and through the
+    per-step launches: every output bit-identical, incl. trajectories, frames, a follow-up action; and == the oracle."""
+    a, case = _run_resident_case(monkeypatch, True, n, steps, capture=capture, fields=fields, aux=aux, seed=n + steps)
+    b, _ = _run_resident_case(monkeypatch, False, n, steps, capture=capture, fields=fields, aux=aux, seed=n + steps)
+    assert a["resident"] is True and b["resident"] is False
+    for k in ("sig", "sig2", "frames", "state"):
+        assert np.array_equal(a[k], b[k]), k
+    if fields:
+        assert np.array_equal(a["ut"], b["ut"]) and np.array_equal(a["ui"], b["ui"])
+    dim, u0, ts, G, d0, d1 = case
+    st, rsig, _ = oracle_integrate(dim, wo.to_abi(u0), ts, G=G, freq=1000.0, d0=flat_design(d0), d1=flat_design(d1),
+                                   ti=ts[0], tf=ts[-1])
+    assert rel_err(a["sig"], rsig) < ENERGY_RTOL
+    if fields:  # u_tot[:, :, k] is the U_tot plane after k steps
+        assert np.array_equal(np.asarray(a["ut"])[:, :, -1].T, st[0])
+        assert np.array_equal(np.asarray(a["ui"])[:, :, -1].T, st[6])
+
+
+def test_resident_kernel_is_the_default_at_700_and_not_used_when_tiles_do_not_fit(monkeypatch):
+    monkeypatch.delenv("WAVES_AMD_FUSED_RESIDENT", raising=False)
+    for n, expect in ((700, True), (1500, False)):
+        dim, ctx = make_ctx(n, "fused")
+        ctx.set_gaussian_source([[3.0, 0.5]], [0.3], [1.0], 1000.0)
+        ctx.integrate(wo.build_tspan(0.0, 1e-5, 4))
+        assert ctx.timing()["resident"] is expect, n
+        ctx.close()

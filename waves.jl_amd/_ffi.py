@@ -289,7 +289,7 @@ class Context:
         self._ck(self._L.wv_get_timing(self._h, C.byref(t)))
         return {"total_ms": t.total_ms, "step_kernel_ms": t.step_kernel_ms,
                 "step_kernel_launches": t.step_kernel_launches, "steps": t.steps,
-                "impl": {1: "staged", 2: "fused"}.get(t.impl, str(t.impl))}
+                "impl": {1: "staged", 2: "fused"}.get(t.impl, str(t.impl)), "resident": bool(t.resident)}
 
     def set_stream(self, stream_handle):
         self._ck(self._L.wv_set_stream(self._h, _vp(stream_handle) if stream_handle else None))

@@ -252,6 +252,7 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
         // halo of the next step: every wave polls the words of its own rows
         // (the next step's cylinders travel while the halo is awaited)
         const Cyl nc = fused_cyl_fetch<AUX, FL, RPT>(p, io.step + 1, t, tid, cx, r);
+        for (int d = 0; d < p.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
         bool ok = false;
         int polls = 0;
         for (; polls < WV_WAIT_POLLS; ++polls) {
@@ -624,6 +625,7 @@ static FusedParams make_params(FusedPlan *pl, const FusedCall &call, int step, c
     p.xch = nullptr;
     p.tag_base = 0;
     p.reduced = 0;
+    p.poll_delay = 0;
     p.abort = nullptr;
     p.stamps = nullptr;
     if (pl->stamps_path) {
@@ -735,6 +737,8 @@ int fused_try_resident(FusedPlan *pl, const FusedCall &call, const FusedStep *st
     p.xch = pl->d_xch;
     p.tag_base = pl->tag_base;
     p.reduced = pl->tiles_aux_zero ? 1 : 0;
+    static const int poll_delay = getenv("WAVES_AMD_POLL_DELAY") ? atoi(getenv("WAVES_AMD_POLL_DELAY")) : 0;
+    p.poll_delay = poll_delay;
     p.abort = pl->d_abort;
     void *args[1] = {&p};
     const hipError_t e = hipLaunchCooperativeKernel(resident_ptr(pl), dim3((unsigned)nt), dim3(512), args, 0, s);
