@@ -7,6 +7,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -552,9 +553,41 @@ int wv_rhs(wv_ctx *c, const float *x, float t, float *k)
     return WV_OK;
 }
 
+// diagnostic (WAVES_AMD_HOSTPROF=1): where the host time of wv_integrate_begin goes, printed at exit
+namespace {
+struct HostProf {
+    bool on = getenv("WAVES_AMD_HOSTPROF") != nullptr;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long calls = 0;
+    std::chrono::steady_clock::time_point t;
+    void start() { if (on) t = std::chrono::steady_clock::now(); }
+    void lap(int k)
+    {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        acc[k] += std::chrono::duration<double, std::micro>(n - t).count();
+        t = n;
+    }
+    ~HostProf()
+    {
+        if (on && calls)
+            fprintf(stderr, "[waves_amd hostprof] per integrate_begin (us): tables %.1f | uploads %.1f | prepare(plan+cull) %.1f | "
+                            "buffers %.1f | enqueue aux %.1f | launch %.1f | tail %.1f  (%ld calls)\n",
+                    acc[0] / calls, acc[1] / calls, acc[2] / calls, acc[3] / calls, acc[4] / calls, acc[5] / calls, acc[6] / calls, calls);
+    }
+};
+HostProf g_hostprof;
+}  // namespace
+
 int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, int want_signal, int want_fields)
 {
     CHECK_CTX(c);
+    g_hostprof.start();
+    if (++g_hostprof.calls == 6) {  // the first calls allocate / load code: not representative
+        for (double &a : g_hostprof.acc) a = 0.0;
+        g_hostprof.calls = 1;
+        g_hostprof.on = g_hostprof.on;
+    }
     if (c->pending) return fail(c, WV_ERR_STATE, "wv_integrate_begin: previous integrate not ended");
     if (!tspan || nsteps < 1) return fail(c, WV_ERR_INVALID, "wv_integrate: tspan NULL or nsteps < 1");
     if (capture && nsteps < 2 * WV_FRAMESKIP)
@@ -576,6 +609,7 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
             if (M > 0) design_at(c, tq[q], c->h_cyl.data() + (size_t)(3 * s + q) * M);
         }
     }
+    g_hostprof.lap(0);
     int rc = ensure(c, &c->d_cyl, &c->cyl_cap, c->h_cyl.size());
     if (rc) return rc;
     if (M > 0)
@@ -584,6 +618,7 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->d_sfac, c->h_sfac.data(), c->h_sfac.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
 
+    g_hostprof.lap(1);
     if (impl == WV_IMPL_FUSED) {
         rc = fused_prepare(c->fused, c->d_frames, c->d_scratch[0], c->d_scratch[1], capture != 0,
                            c->has_source ? c->d_G : nullptr, c->d_cyl, M > 0 ? c->h_cyl.data() : nullptr, M, 3 * nsteps,
@@ -592,6 +627,7 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
         if (fused_generation(c->fused) != c->elast_generation) c->elast_valid = false;
         c->elast_generation = fused_generation(c->fused);
     }
+    g_hostprof.lap(2);
     const int nblocks = impl == WV_IMPL_STAGED ? staged_energy_blocks(c->grid) : fused_energy_blocks(c->fused);
     if (want_signal) {
         rc = ensure(c, &c->d_epart, &c->epart_cap, (size_t)(nsteps + 1) * nblocks * 3);
@@ -614,6 +650,7 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
         }
     }
 
+    g_hostprof.lap(3);
     hipStream_t st = c->stream;
     HIPCHK(c, hipEventRecord(c->ev0, st));
 
@@ -685,6 +722,7 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
         if (c->profiling && impl == WV_IMPL_STAGED) HIPCHK(c, hipEventRecord(c->kev[2 * (s - 1) + 1], st));
         cur = out;
     }
+    g_hostprof.lap(4);
     c->prof_launches = nsteps * (impl == WV_IMPL_STAGED ? 4 : 1);
     c->prof_events = nsteps;
     bool resident = false;
@@ -710,6 +748,7 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
             }
         }
     }
+    g_hostprof.lap(5);
     HIPCHK(c, hipGetLastError());
     if (want_signal) {
         launch_energy_final(c->d_epart, nsteps + 1, nblocks, c->dOmega, c->d_signal, st);
@@ -727,6 +766,7 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     c->timing = wv_timing{};
     c->timing.steps = nsteps;
     c->timing.impl = impl;
+    g_hostprof.lap(6);
     c->timing.resident = resident || (impl == WV_IMPL_FUSED && !c->profiling && fused_last_resident(c->fused)) ? 1 : 0;
     return WV_OK;
 }

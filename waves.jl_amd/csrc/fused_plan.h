@@ -326,8 +326,9 @@ inline void plan_build_cyl(HostPlan &pl, const float *x, const float *y, const C
     // The hardware gives launch position b the CU b mod C, so positions b and b + C share a CU -- and its four SIMDs --
     // for the whole call, while positions n-C .. C-1 have a CU to themselves.  Every tile advances at the pace of the
     // slowest one, so: the heaviest 2C-n tiles get the CUs of their own, the next heaviest are paired with the lightest.
-    // (Measured on MI355X, 700^2: a tile that evaluates cylinders takes ~1.8x the arithmetic of a plain interior tile,
-    // a corner tile ~1.7x, PML strips ~1.2x.)  L2 locality is irrelevant here: resident tiles exchange halos through
+    // (Measured on MI355X, 700^2: alone on a CU a corner tile takes ~1.5x and a tile that evaluates cylinders ~1.35x the
+    // time of a plain interior tile; two tiles sharing a CU take ~1.3x the time of the slower one alone.  Pairing the two
+    // kinds of PML strip with each other instead of with light interior tiles costs 9 %.)  L2 locality is irrelevant here: resident tiles exchange halos through
     // memory.  Placement only affects speed, never results.
     const int n = (int)pl.tiles.size();
     if (pair_cus > 0 && pl.band_begin.size() == 2 && n > pair_cus && n <= 2 * pair_cus) {
