@@ -116,9 +116,10 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=40, help="integration steps of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--grid", type=int, default=N_GRID, help="grid points per axis (700 = the metric's configuration)")
     ap.add_argument("--pml-width", type=float, default=2.0)
-    ap.add_argument("--batch-envs", type=int, default=8,
+    ap.add_argument("--batch-envs", type=int, default=4,
                     help="extra (untimed-for-`value`) measurement: this many independent envs stepped concurrently on the "
-                         "GPU, BASELINE config 3's 8-per-GPU shape (0 = skip)")
+                         "GPU, the shape of BASELINE config 3 (0 = skip).  4 is where the aggregate peaks on one MI355X; "
+                         "config 3's literal 8 per GPU gives about half of it (measured)")
     args = ap.parse_args()
 
     import torch  # first: the HIP runtime both torch and libwaves_amd use is then torch's

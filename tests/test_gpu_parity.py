@@ -341,6 +341,8 @@ def test_recycled_device_memory_does_not_leak_into_results():
 
 # ---- the resident kernel (all steps of a call in one cooperative launch, tagged halo exchange) ------------------------
 def _run_resident_case(monkeypatch, resident, n, steps, *, capture, fields, aux, seed):
+    import gc
+    gc.collect()  # contexts earlier tests left to the collector: the resident path needs the device to itself
     monkeypatch.setenv("WAVES_AMD_FUSED_RESIDENT", "1" if resident else "0")
     rng = np.random.default_rng(seed)
     dim, ctx = make_ctx(n, "fused")
@@ -386,6 +388,8 @@ def test_resident_kernel_equals_single_step_kernels_and_oracle(monkeypatch, n, s
 
 
 def test_resident_kernel_is_the_default_at_700_and_not_used_when_tiles_do_not_fit(monkeypatch):
+    import gc
+    gc.collect()
     monkeypatch.delenv("WAVES_AMD_FUSED_RESIDENT", raising=False)
     for n, expect in ((700, True), (1500, False)):
         dim, ctx = make_ctx(n, "fused")
@@ -393,3 +397,30 @@ def test_resident_kernel_is_the_default_at_700_and_not_used_when_tiles_do_not_fi
         ctx.integrate(wo.build_tspan(0.0, 1e-5, 4))
         assert ctx.timing()["resident"] is expect, n
         ctx.close()
+
+
+def test_resident_kernel_only_when_the_context_has_the_device_to_itself(monkeypatch):
+    """Several environments on one GPU step concurrently on their streams: they use the single-step kernels (a resident
+    kernel occupies the whole device for the duration of a call).  Same bits either way."""
+    import gc
+    gc.collect()
+    monkeypatch.delenv("WAVES_AMD_FUSED_RESIDENT", raising=False)
+    ts = wo.build_tspan(0.0, 1e-5, 24)
+
+    def go(ctx):
+        ctx.set_gaussian_source([[1.0, -2.0]], [0.4], [1.0], 1000.0)
+        ctx.reset()
+        sig, _, _ = ctx.integrate(ts, capture_frames=True)
+        return sig, ctx.get_frames(), ctx.timing()["resident"]
+
+    dim, a = make_ctx(300, "fused")
+    sa, fa, ra = go(a)
+    dim, b = make_ctx(300, "fused")
+    sb, fb, rb = go(b)
+    sa2, fa2, ra2 = go(a)
+    b.close()
+    sa3, fa3, ra3 = go(a)
+    a.close()
+    assert (ra, rb, ra2, ra3) == (True, False, False, True)
+    for s_, f_ in ((sb, fb), (sa2, fa2), (sa3, fa3)):
+        assert np.array_equal(s_, sa) and np.array_equal(f_, fa)

@@ -7,6 +7,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
 #include <string>
 #include <vector>
@@ -55,6 +56,7 @@ struct wv_ctx {
     float *d_sfac = nullptr;   // per-step source time factors [nsteps][3]
     size_t sfac_cap = 0;
     std::vector<FusedStep> fsteps;
+    bool counted = false;  // this ctx is included in g_live_ctx
     int prof_launches = 0, prof_events = 0;  // profiling mode: integrator launches / event pairs of the last call
     float *d_elast = nullptr;  // per-block energy partials of the state the last integrate ended on
     size_t elast_cap = 0;
@@ -206,9 +208,17 @@ int wv_device_count(int *count)
     return WV_OK;
 }
 
+// Contexts alive per device.  The resident step kernel owns the whole device for the duration of a call (cooperative
+// launch, every tile resident), which is the fastest way to run ONE environment; several environments stepped
+// concurrently on one GPU are better served by the single-step kernels, whose launches interleave on the streams
+// (measured at 700^2, 4 envs: 48 vs 22-37 Gcell-updates/s) -- so the resident path is taken only by a context that has
+// the device to itself within this process.
+static std::atomic<int> g_live_ctx[64];
+
 int wv_destroy(wv_ctx *c)
 {
     if (!c) return WV_OK;
+    if (c->counted) g_live_ctx[c->cfg.device & 63]--;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     float *bufs[] = {c->d_x, c->d_y, c->d_sx, c->d_sy, c->d_frames, c->d_scratch[0], c->d_scratch[1], c->d_yA, c->d_yB,
@@ -321,6 +331,8 @@ int wv_create(const wv_config *cfg, const float *x, const float *y, wv_ctx **out
         wv_destroy(c);
         return fail(nullptr, WV_ERR_HIP, "wv_create: fused plan allocation failed");
     }
+    c->counted = true;
+    g_live_ctx[cfg->device & 63]++;
     *out = c;
     return WV_OK;
 }
@@ -620,6 +632,7 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
 
     g_hostprof.lap(1);
     if (impl == WV_IMPL_FUSED) {
+        fused_allow_resident(c->fused, g_live_ctx[c->cfg.device & 63] <= 1);
         rc = fused_prepare(c->fused, c->d_frames, c->d_scratch[0], c->d_scratch[1], capture != 0,
                            c->has_source ? c->d_G : nullptr, c->d_cyl, M > 0 ? c->h_cyl.data() : nullptr, M, 3 * nsteps,
                            c->stream);

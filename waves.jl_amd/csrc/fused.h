@@ -55,6 +55,7 @@ bool fused_last_resident(const FusedPlan *p);  // the last fused_run took the si
 // All steps in one cooperative launch of k_steps_resident.  Returns 0 when launched, -1 when this call cannot take that
 // path (more tiles than the device holds at once, a single step, diagnostics ...; the caller then launches step by
 // step), 1 on a HIP error.  fused_run tries this first.
+void fused_allow_resident(FusedPlan *p, bool allow);  // per call: false keeps this call on the single-step kernels
 int fused_try_resident(FusedPlan *p, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s);
 void fused_variant_counts(const FusedPlan *p, int out[4]);  // tiles per field set: NONE, PX, PY, ALL
 

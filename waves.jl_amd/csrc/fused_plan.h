@@ -13,7 +13,8 @@ namespace wv {
 struct HostPlan {
     int nx = 0, ny = 0;
     int RYF = 0, RYB = 0, RYP = 0;  // region rows of AUX_NONE tiles / AUX_PX+AUX_PY tiles / AUX_ALL tiles
-    std::vector<TileDesc> tiles;    // launch order: band-major, inside a band see plan_order
+    std::vector<TileDesc> tiles;    // launch order: band-major, inside a band see plan_order; refined per call (plan_build_cyl)
+    std::vector<TileDesc> base;     // the order plan_build_tiles produced: every per-call refinement starts from it
     std::vector<int> band_begin;    // band b = tiles[band_begin[b] .. band_begin[b+1]); bands are contiguous ranges of
                                     // x-strips, so a band's tiles only read halo cells of the two adjacent bands
     int count[4] = {0, 0, 0, 0};    // tiles per field set
@@ -243,7 +244,37 @@ inline bool plan_build_tiles(HostPlan &pl, int nx, int ny, int RYF, int RYB, int
         pl.tiles.insert(pl.tiles.end(), ordered.begin(), ordered.end());
         pl.band_begin.push_back((int)pl.tiles.size());
     }
+    pl.base = pl.tiles;
     return pl.tiles.size() == all.size() && a == nstrips;
+}
+
+// Launch order for the resident kernel (all tiles on the device at once, pair_cus = its CU count C, n <= 2C tiles).
+// The hardware gives launch position b the CU b mod C, so positions b and b + C share a CU -- and its four SIMDs -- for
+// the whole call, while positions n-C .. C-1 have a CU to themselves.  Every tile advances at the pace of the slowest
+// one, so: the heaviest 2C-n tiles get the CUs of their own, the next heaviest are paired with the lightest.
+// (Measured on MI355X, 700^2: alone on a CU a corner tile takes ~1.5x and a tile that evaluates cylinders ~1.35x the
+// time of a plain interior tile; two tiles sharing a CU take ~1.3x the time of the slower one alone.  Pairing the two
+// kinds of PML strip with each other instead of with light interior tiles costs 9 %.)  L2 locality is irrelevant here:
+// resident tiles exchange halos through memory.  Placement only affects speed, never results.
+inline void plan_pair_order(HostPlan &pl, int pair_cus)
+{
+    const int n = (int)pl.tiles.size();
+    if (!(pair_cus > 0 && pl.band_begin.size() == 2 && n > pair_cus && n <= 2 * pair_cus)) return;
+    auto weight = [&](const TileDesc &t) {
+        const int RY = t.aux == AUX_NONE ? pl.RYF : (t.aux == AUX_ALL ? pl.RYP : pl.RYB);
+        const double fill = (double)(t.oy + 2 * FT_H) / RY;
+        const double set = t.aux == AUX_NONE ? 1.0 : (t.aux == AUX_ALL ? 1.75 : 1.22);
+        const int nc = t.cyl_count < 0 ? 8 : t.cyl_count;
+        return fill * set * (nc > 0 ? 1.6 + 0.2 * (nc - 1) : 1.0);
+    };
+    std::vector<TileDesc> byw = pl.tiles;
+    std::stable_sort(byw.begin(), byw.end(), [&](const TileDesc &a, const TileDesc &c) { return weight(a) > weight(c); });
+    const int C = pair_cus, alone = 2 * C - n, pairs = n - C;
+    for (int i = 0; i < alone; ++i) pl.tiles[pairs + i] = byw[i];
+    for (int i = 0; i < pairs; ++i) {
+        pl.tiles[i] = byw[alone + i];
+        pl.tiles[C + i] = byw[n - 1 - i];
+    }
 }
 
 // Per-tile list of the cylinders whose disc can reach the tile's region at ANY of the `rows` stage times of this
@@ -253,8 +284,10 @@ inline void plan_build_cyl(HostPlan &pl, const float *x, const float *y, const C
                            std::vector<int> &idx, bool resort = true, int pair_cus = 0)
 {
     idx.clear();
+    pl.tiles = pl.base;
     if (M <= 0) {
         for (TileDesc &t : pl.tiles) t.cyl_begin = t.cyl_count = 0;
+        plan_pair_order(pl, pair_cus);
         return;
     }
     struct Box { double x0, x1, y0, y1, r; bool ok; };
@@ -322,32 +355,7 @@ inline void plan_build_cyl(HostPlan &pl, const float *x, const float *y, const C
             for (int k = lo + g; k < hi; k += 8) pl.tiles[k] = grp[q++];
         }
     }
-    // Launch order for the resident kernel (all tiles on the device at once, pair_cus = its CU count C, n <= 2C tiles).
-    // The hardware gives launch position b the CU b mod C, so positions b and b + C share a CU -- and its four SIMDs --
-    // for the whole call, while positions n-C .. C-1 have a CU to themselves.  Every tile advances at the pace of the
-    // slowest one, so: the heaviest 2C-n tiles get the CUs of their own, the next heaviest are paired with the lightest.
-    // (Measured on MI355X, 700^2: alone on a CU a corner tile takes ~1.5x and a tile that evaluates cylinders ~1.35x the
-    // time of a plain interior tile; two tiles sharing a CU take ~1.3x the time of the slower one alone.  Pairing the two
-    // kinds of PML strip with each other instead of with light interior tiles costs 9 %.)  L2 locality is irrelevant here: resident tiles exchange halos through
-    // memory.  Placement only affects speed, never results.
-    const int n = (int)pl.tiles.size();
-    if (pair_cus > 0 && pl.band_begin.size() == 2 && n > pair_cus && n <= 2 * pair_cus) {
-        auto weight = [&](const TileDesc &t) {
-            const int RY = t.aux == AUX_NONE ? pl.RYF : (t.aux == AUX_ALL ? pl.RYP : pl.RYB);
-            const double fill = (double)(t.oy + 2 * FT_H) / RY;
-            const double set = t.aux == AUX_NONE ? 1.0 : (t.aux == AUX_ALL ? 1.75 : 1.22);
-            const int nc = t.cyl_count < 0 ? 8 : t.cyl_count;
-            return fill * set * (nc > 0 ? 1.6 + 0.2 * (nc - 1) : 1.0);
-        };
-        std::vector<TileDesc> byw = pl.tiles;
-        std::stable_sort(byw.begin(), byw.end(), [&](const TileDesc &a, const TileDesc &c) { return weight(a) > weight(c); });
-        const int C = pair_cus, alone = 2 * C - n, pairs = n - C;
-        for (int i = 0; i < alone; ++i) pl.tiles[pairs + i] = byw[i];
-        for (int i = 0; i < pairs; ++i) {
-            pl.tiles[i] = byw[alone + i];
-            pl.tiles[C + i] = byw[n - 1 - i];
-        }
-    }
+    plan_pair_order(pl, pair_cus);
 }
 
 }  // namespace wv

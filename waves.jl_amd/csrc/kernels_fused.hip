@@ -405,6 +405,7 @@ struct FusedPlan {
     const char *stamps_path = nullptr;
     // k_steps_resident (all steps of a call in one cooperative launch)
     bool use_resident = true;     // WAVES_AMD_FUSED_RESIDENT=0 disables
+    bool allow_resident = true;   // set per call by the owner (false: other contexts share the device)
     int resident_capacity = -1;   // blocks of k_steps_resident the device holds at once (-1: not asked yet)
     int cu_count = 0;
     StepIO *d_steps = nullptr;
@@ -675,7 +676,7 @@ static const void *resident_ptr(const FusedPlan *pl)
 // blocks of k_steps_resident the device holds at once (0: the resident path is not available)
 static int resident_capacity(FusedPlan *pl)
 {
-    if (!pl->use_resident || pl->nbands != 1) return 0;
+    if (!pl->use_resident || !pl->allow_resident || pl->nbands != 1) return 0;
     if (pl->resident_capacity < 0) {
         int per_cu = 0, dev = 0;
         hipDeviceProp_t prop;
@@ -828,6 +829,7 @@ int fused_run(FusedPlan *pl, const FusedCall &call, const FusedStep *steps, int 
 }
 
 int fused_generation(const FusedPlan *p) { return p->generation; }
+void fused_allow_resident(FusedPlan *p, bool allow) { p->allow_resident = allow; }
 bool fused_last_resident(const FusedPlan *p) { return p->last_resident; }
 
 // diagnostic: write the phase stamps of the LAST launched step, with the tile list, to WAVES_AMD_STAMPS (text)
