@@ -424,3 +424,55 @@ def test_resident_kernel_only_when_the_context_has_the_device_to_itself(monkeypa
     assert (ra, rb, ra2, ra3) == (True, False, False, True)
     for s_, f_ in ((sb, fb), (sa2, fa2), (sa3, fa3)):
         assert np.array_equal(s_, sa) and np.array_equal(f_, fa)
+
+
+def _ring_run(ctx, steps, calls):
+    out = []
+    ctx.set_gaussian_source([[1.0, -2.0]], [0.4], [1.0], 1000.0)
+    ctx.reset()
+    t0 = 0.0
+    for _ in range(calls):
+        ts = wo.build_tspan(f32(t0), 1e-5, steps)
+        sig, _, _ = ctx.integrate(ts, capture_frames=True)
+        out.append((sig, ctx.get_frames()))
+        t0 = ts[-1]
+    return out
+
+
+def test_resident_exchange_tags_wrap_around(monkeypatch):
+    """The exchange words carry a 32-bit step tag that grows from call to call; shortly before it would wrap the buffer
+    is cleared and the count restarts.  Start it 16 steps below the threshold and cross it: same bits as a fresh one."""
+    import gc
+    gc.collect()
+    monkeypatch.delenv("WAVES_AMD_FUSED_RESIDENT", raising=False)
+    dim, ref = make_ctx(200, "fused")
+    want = _ring_run(ref, 30, 3)
+    ref.close()
+    monkeypatch.setenv("WAVES_AMD_TAG_BASE", hex(0xFFFF0000 - 46))
+    dim, ctx = make_ctx(200, "fused")
+    got = _ring_run(ctx, 30, 3)
+    assert ctx.timing()["resident"] is True
+    ctx.close()
+    for (sa, fa), (sb, fb) in zip(want, got):
+        assert np.array_equal(sa, sb) and np.array_equal(fa, fb)
+
+
+def test_resident_kernel_gives_up_cleanly_and_the_context_recovers(monkeypatch):
+    """A resident tile that never sees its neighbours' words must not hang the device: with the poll budget forced to
+    one, some wave gives up, the launch drains, wv_integrate reports it -- and the same context works again afterwards."""
+    import gc
+    gc.collect()
+    monkeypatch.delenv("WAVES_AMD_FUSED_RESIDENT", raising=False)
+    dim, ref = make_ctx(300, "fused")
+    want = _ring_run(ref, 40, 1)
+    ref.close()
+    dim, ctx = make_ctx(300, "fused")
+    monkeypatch.setenv("WAVES_AMD_WAIT_POLLS", "1")
+    with pytest.raises(w._ffi.WavesAmdError) as e:
+        _ring_run(ctx, 40, 1)
+    assert "gave up" in str(e.value)
+    monkeypatch.delenv("WAVES_AMD_WAIT_POLLS")
+    got = _ring_run(ctx, 40, 1)   # reset() + a fresh call on the same context
+    assert ctx.timing()["resident"] is True
+    ctx.close()
+    assert np.array_equal(want[0][0], got[0][0]) and np.array_equal(want[0][1], got[0][1])

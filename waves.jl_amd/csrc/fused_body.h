@@ -95,6 +95,7 @@ struct FusedParams {
     int *abort;                // set when a wait gave up: every tile then leaves the kernel
     int reduced;               // the tiles use reduced field sets (auxiliary fields are zero outside the PML)
     int poll_delay;            // tuning: idle time before the first halo poll of a step, in units of 64 clocks
+    int max_polls;             // a wave gives up (and the launch drains) after this many polls of one halo
     unsigned long long *stamps;  // diagnostic: [ntiles][16] shader-clock stamps per phase, or nullptr (normal runs)
 };
 
@@ -455,8 +456,11 @@ WV_HD void fused_xch_store(const FusedParams &p, unsigned tag, const TileDesc &t
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int j = 0; j < NS; ++j)
+            for (int j = 0; j < NS; ++j) {
+#ifndef WV_XCH_NOSTORE  // (timing experiment only)
                 xch_put(xch_word(base + (size_t)(6 * s + aux_plane(AUX, j)) * p.P, off), xch_pack(r.y[rr][s][j], tag));
+#endif
+            }
     }
 }
 

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_step_fused(FusedParams p_)  // 4
 // A wave polls its halo words at most WV_WAIT_POLLS times (seconds; a healthy wait takes microseconds), then raises
 // *abort; every wave watches that word while it polls and the block leaves together: the kernel always drains and the
 // host reports the failure.
-constexpr int WV_WAIT_POLLS = 1 << 20;
+constexpr int WV_WAIT_POLLS = 1 << 20;  // default of FusedParams::max_polls (WAVES_AMD_WAIT_POLLS overrides: tests)
 
 // The step loop must compile like a sequence of single-step bodies: only the tile's registers are carried from one
 // step to the next.  Left alone, the compiler hoists every loop-invariant load, index and address out of the loop and
@@ -255,7 +255,7 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
         for (int d = 0; d < p.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
         bool ok = false;
         int polls = 0;
-        for (; polls < WV_WAIT_POLLS; ++polls) {
+        for (; polls < p.max_polls; ++polls) {
             ok = __all(fused_xch_load<AUX, NW, RPT>(p, tag, t, tid, r));
             if (ok) break;
             const int ab = ((tid & 63) == 0) ? __hip_atomic_load(p.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
@@ -406,6 +406,7 @@ struct FusedPlan {
     // k_steps_resident (all steps of a call in one cooperative launch)
     bool use_resident = true;     // WAVES_AMD_FUSED_RESIDENT=0 disables
     bool allow_resident = true;   // set per call by the owner (false: other contexts share the device)
+    int max_polls = WV_WAIT_POLLS;
     int resident_capacity = -1;   // blocks of k_steps_resident the device holds at once (-1: not asked yet)
     int cu_count = 0;
     StepIO *d_steps = nullptr;
@@ -413,6 +414,7 @@ struct FusedPlan {
     std::vector<StepIO> h_steps;  // what d_steps holds
     unsigned long long *d_xch = nullptr;  // tagged halo exchange buffer [2][12][P], see fused_xch_*
     unsigned tag_base = 0;        // tags handed out so far (the buffer never holds a tag above it)
+    unsigned tag_base_init = 0;   // diagnostic: first tag base after the buffer is created
     int *d_abort = nullptr;
     int *h_abort = nullptr;       // pinned copy, valid after the stream has been waited for
     bool abort_pending = false;   // a resident launch is in flight (or finished) whose verdict has not been looked at
@@ -444,6 +446,7 @@ FusedPlan *fused_create(const Grid &g, const float *x, const float *y, const flo
     if (const char *e = getenv("WAVES_AMD_FUSED_BANDS")) p->nbands = atoi(e) > 0 ? atoi(e) : 1;
     if (const char *e = getenv("WAVES_AMD_FUSED_GRAPH")) p->use_graph = atoi(e) != 0;
     if (const char *e = getenv("WAVES_AMD_FUSED_RESIDENT")) p->use_resident = atoi(e) != 0;
+    if (const char *e = getenv("WAVES_AMD_TAG_BASE")) p->tag_base_init = (unsigned)strtoul(e, nullptr, 0);  // tests: wrap
     if (hipMalloc((void **)&p->d_flag, sizeof(int)) != hipSuccess || hipMalloc((void **)&p->d_abort, sizeof(int)) != hipSuccess ||
         hipHostMalloc((void **)&p->h_abort, sizeof(int), hipHostMallocDefault) != hipSuccess ||
         hipMemset(p->d_abort, 0, sizeof(int)) != hipSuccess) {
@@ -627,6 +630,7 @@ static FusedParams make_params(FusedPlan *pl, const FusedCall &call, int step, c
     p.tag_base = 0;
     p.reduced = 0;
     p.poll_delay = 0;
+    p.max_polls = 0;
     p.abort = nullptr;
     p.stamps = nullptr;
     if (pl->stamps_path) {
@@ -706,7 +710,8 @@ int fused_try_resident(FusedPlan *pl, const FusedCall &call, const FusedStep *st
             return -1;
         }
         if (hipMemsetAsync(pl->d_xch, 0, xwords * sizeof(unsigned long long), s) != hipSuccess) return 1;
-        pl->tag_base = 0;
+        pl->tag_base = pl->tag_base_init;
+        pl->tag_base_init = 0;
     }
     // the step table (unchanged from call to call in a rollout: uploaded only when it differs)
     std::vector<StepIO> tab((size_t)nsteps);
@@ -740,6 +745,8 @@ int fused_try_resident(FusedPlan *pl, const FusedCall &call, const FusedStep *st
     p.reduced = pl->tiles_aux_zero ? 1 : 0;
     static const int poll_delay = getenv("WAVES_AMD_POLL_DELAY") ? atoi(getenv("WAVES_AMD_POLL_DELAY")) : 0;
     p.poll_delay = poll_delay;
+    const char *mp = getenv("WAVES_AMD_WAIT_POLLS");  // diagnostic, read per call (tests force a give-up with it)
+    p.max_polls = (mp && atoi(mp) > 0) ? atoi(mp) : pl->max_polls;
     p.abort = pl->d_abort;
     void *args[1] = {&p};
     const hipError_t e = hipLaunchCooperativeKernel(resident_ptr(pl), dim3((unsigned)nt), dim3(512), args, 0, s);
