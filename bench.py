@@ -63,10 +63,27 @@ def cpu_baseline(n_steps: int):
     co.integrate(dim.x, dim.y, sx, sx, wo.WATER, 1e-5, st, ts, G=wo.to_abi(G), freq=1000.0, d0=flat(a), d1=flat(b),
                  ti=0.0, tf=ts[-1], nthreads=1)
     dt = time.perf_counter() - t0
-    return {"value": round(N_GRID * N_GRID * n_steps / dt / 1e6, 3), "unit": "Mcell-updates/s", "cores": 1,
-            "kind": "port",
-            "sample": f"{n_steps} integration steps of the same 700^2 triple-ring workload ({dt:.1f} s), "
-                      "oracle/waves_oracle.c single thread"}
+    out = {"value": round(N_GRID * N_GRID * n_steps / dt / 1e6, 3), "unit": "Mcell-updates/s", "cores": 1,
+           "kind": "port",
+           "sample": f"{n_steps} integration steps of the same 700^2 triple-ring workload ({dt:.1f} s), "
+                     "oracle/waves_oracle.c single thread"}
+    # for orientation only: the same restatement with its OpenMP loops on all the cores this process may use (the
+    # reference's own CPU path is single-threaded: Julia sparse `*` and broadcast, no threads enabled in its scripts)
+    try:
+        nth = len(os.sched_getaffinity(0))
+    except Exception:
+        nth = os.cpu_count() or 1
+    nth = min(nth, 16)  # the CPU share of a one-GPU box (its host may show hundreds of cores it will not give us)
+    if nth > 1:
+        st = np.zeros((12, N_GRID, N_GRID), f32)
+        ts2 = wo.build_tspan(0.0, 1e-5, 2 * n_steps)
+        t0 = time.perf_counter()
+        co.integrate(dim.x, dim.y, sx, sx, wo.WATER, 1e-5, st, ts2, G=wo.to_abi(G), freq=1000.0, d0=flat(a), d1=flat(b),
+                     ti=0.0, tf=ts2[-1], nthreads=nth)
+        dt2 = time.perf_counter() - t0
+        out["all_cores"] = {"value": round(N_GRID * N_GRID * 2 * n_steps / dt2 / 1e6, 3), "cores": nth,
+                            "sample": f"{2 * n_steps} steps, OpenMP ({dt2:.1f} s)"}
+    return out
 
 
 def batched_envs(w, dim, ds, dev, impl, n_envs, pml_width, actions=6):
