@@ -4,6 +4,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "fused_body.h"
@@ -267,13 +268,15 @@ inline void plan_pair_order(HostPlan &pl, int pair_cus)
         const int nc = t.cyl_count < 0 ? 8 : t.cyl_count;
         return fill * set * (nc > 0 ? 1.6 + 0.2 * (nc - 1) : 1.0);
     };
-    std::vector<TileDesc> byw = pl.tiles;
-    std::stable_sort(byw.begin(), byw.end(), [&](const TileDesc &a, const TileDesc &c) { return weight(a) > weight(c); });
+    std::vector<std::pair<double, int>> key(n);  // (−weight, position): ascending sort = heaviest first, ties in order
+    for (int i = 0; i < n; ++i) key[i] = {-weight(pl.tiles[i]), i};
+    std::sort(key.begin(), key.end());
+    const std::vector<TileDesc> src = pl.tiles;
     const int C = pair_cus, alone = 2 * C - n, pairs = n - C;
-    for (int i = 0; i < alone; ++i) pl.tiles[pairs + i] = byw[i];
+    for (int i = 0; i < alone; ++i) pl.tiles[pairs + i] = src[key[i].second];
     for (int i = 0; i < pairs; ++i) {
-        pl.tiles[i] = byw[alone + i];
-        pl.tiles[C + i] = byw[n - 1 - i];
+        pl.tiles[i] = src[key[alone + i].second];
+        pl.tiles[C + i] = src[key[n - 1 - i].second];
     }
 }
 
@@ -342,7 +345,9 @@ inline void plan_build_cyl(HostPlan &pl, const float *x, const float *y, const C
     // Launch order refinement: inside each XCD group (launch positions congruent modulo 8 -- or all tiles when the order
     // is not XCD-aware) the tiles that will take longest (cylinders to evaluate, more fields) go first: the kernel ends
     // when its slowest tile ends, and launch positions are worth up to ~1 us of head start.
-    for (size_t b = 0; resort && b + 1 < pl.band_begin.size(); ++b) {
+    const int ntile = (int)pl.tiles.size();
+    const bool will_pair = pair_cus > 0 && pl.band_begin.size() == 2 && ntile > pair_cus && ntile <= 2 * pair_cus;
+    for (size_t b = 0; resort && !will_pair && b + 1 < pl.band_begin.size(); ++b) {
         const int lo = pl.band_begin[b], hi = pl.band_begin[b + 1];
         for (int g = 0; g < 8; ++g) {
             std::vector<TileDesc> grp;
