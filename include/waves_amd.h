@@ -116,6 +116,14 @@ int wv_set_source_shape(wv_ctx *ctx, const float *shape /* nx*ny or NULL */, flo
 int wv_set_gaussian_source(wv_ctx *ctx, int K, const float *mu, const float *sigma, const float *a, float freq);
 int wv_get_source_shape(wv_ctx *ctx, float *shape /* nx*ny */);
 
+/* The observation of RLBase.state(env), src/env.jl:132-137:
+ *     x = imresize(cat(env.wave[:, :, 1, :], env.source.shape, dims = 3), env.resolution)
+ * out is (rx, ry, 4) column-major: U_tot of the three frames of env.wave, then the source shape (zeros for NoSource),
+ * each resized on the device from (nx, ny) to (rx, ry); 1 <= rx <= nx, 1 <= ry <= ny (the reference asserts
+ * size(dim) .> resolution, src/env.jl:52).  imresize belongs to Images.jl (third-party, unpinned): the rule implemented
+ * is stated in kernels_aux.hip (k_observation); the test-suite's CPU restatement of it is imresize_linear. */
+int wv_observation(wv_ctx *ctx, int rx, int ry, float *out /* rx*ry*4 */);
+
 /* C = t -> speed(DesignInterpolator(initial, final, ti, tf)(t), grid, c0).  src/env.jl:95-99, src/designs.jl:274-292.
  * A design is M cylinders (a Cloak is passed stacked: config cylinders then the core, src/designs.jl:228,133-138):
  * pos is M x 2 column-major (all x, then all y, like Julia's Matrix), r and c have M entries.  M == 0 is NoDesign

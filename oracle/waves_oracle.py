@@ -739,6 +739,32 @@ def energies(u_tot: np.ndarray, u_inc: np.ndarray, dOmega, T=f32) -> np.ndarray:
     return np.array([s(u_tot) * d, s(u_inc) * d, s(u_sc) * d], dtype=T)
 
 
+
+def imresize_linear(w, resolution):
+    """`imresize(w, resolution)` of src/env.jl:135 for an (nx, ny[, k]) array resized on its first two axes.
+
+    imresize is Images.jl / ImageTransformations (third-party; version unpinned, Manifest git-ignored; not under
+    /root/reference).  Its published rule, restated: linear B-spline interpolation of the original, flat beyond the edge
+    pixels, sampled pixel-centre aligned at x_o = (n / r) * (i - 0.5) + 0.5 (1-based) on every resized axis, evaluated
+    in Float64 and rounded once to the element type; axes that keep their size are copied.  The summation order below
+    (x inside, y outside) is this project's definition.  PARITY UNPINNED: no fixture of the reference covers it."""
+    w = np.asarray(w)
+    nx, ny = w.shape[:2]
+    rx, ry = resolution
+    xo = np.clip((nx / rx) * (np.arange(1, rx + 1, dtype=np.float64) - 0.5) + 0.5 - 1.0, 0.0, nx - 1.0)
+    yo = np.clip((ny / ry) * (np.arange(1, ry + 1, dtype=np.float64) - 0.5) + 0.5 - 1.0, 0.0, ny - 1.0)
+    i0 = np.floor(xo).astype(np.int64)
+    j0 = np.floor(yo).astype(np.int64)
+    i1 = np.minimum(i0 + 1, nx - 1)
+    j1 = np.minimum(j0 + 1, ny - 1)
+    fx = (xo - i0).reshape((rx, 1) + (1,) * (w.ndim - 2))
+    fy = (yo - j0).reshape((1, ry) + (1,) * (w.ndim - 2))
+    wd = w.astype(np.float64)
+    lo = (1.0 - fx) * wd[i0][:, j0] + fx * wd[i1][:, j0]
+    hi = (1.0 - fx) * wd[i0][:, j1] + fx * wd[i1][:, j1]
+    return ((1.0 - fy) * lo + fy * hi).astype(w.dtype)
+
+
 class WaveEnv:
     """src/env.jl:14-121."""
 
@@ -784,6 +810,13 @@ class WaveEnv:
 
     def reward(self):  # :147-149
         return self.signal.sum()
+
+    def state(self):  # :132-137  (x only; dim, tspan and design ride along unchanged)
+        shape = getattr(self.source, "shape", None)
+        if shape is None:
+            shape = np.zeros(self.dim.size(), dtype=self.T)
+        w = np.concatenate([self.wave[:, :, 0, :], np.asarray(shape, dtype=self.T)[:, :, None]], axis=2)
+        return imresize_linear(w, self.resolution)
 
     def __call__(self, action, return_fields=True):
         """src/env.jl:91-121."""

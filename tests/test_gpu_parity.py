@@ -476,3 +476,42 @@ def test_resident_kernel_gives_up_cleanly_and_the_context_recovers(monkeypatch):
     assert ctx.timing()["resident"] is True
     ctx.close()
     assert np.array_equal(want[0][0], got[0][0]) and np.array_equal(want[0][1], got[0][1])
+
+
+# ---- the observation path -------------------------------------------------------------------------
+@pytest.mark.parametrize("n,res", [(700, (128, 128)), (256, (128, 128)), (257, (100, 90)), (64, (64, 63)), (96, (1, 5))])
+def test_observation_resized_on_the_device_equals_the_restated_rule(n, res):
+    """wv_observation == imresize_linear(cat(U_tot frames, source shape)) bit for bit (Float64 evaluation, one rounding).
+    Parity with Images.jl itself is unpinned (third-party, absent): see waves_oracle.imresize_linear."""
+    rng = np.random.default_rng(n)
+    dim, ctx = make_ctx(n, "fused")
+    wave = np.asfortranarray(rng.standard_normal((n, n, 12, 3)).astype(f32))
+    ctx.set_frames(wave)
+    G = wo.build_normal(wo.build_grid(dim), np.array([[2.0, -3.0]]), np.array([0.7]), np.array([1.0]))
+    ctx.set_source_shape(G, 1000.0)
+    got = ctx.observation(*res)
+    want = wo.imresize_linear(np.concatenate([wave[:, :, 0, :], G[:, :, None]], axis=2), res)
+    assert got.shape == res + (4,) and np.array_equal(got, want)
+    ctx.set_source_shape(None, 0.0)                      # NoSource: the shape channel is zero
+    assert np.array_equal(ctx.observation(*res)[:, :, 3], np.zeros(res, f32))
+    with pytest.raises(w._ffi.WavesAmdError):
+        ctx.observation(n + 1, 4)
+    ctx.close()
+
+
+def test_env_state_is_the_resized_observation():
+    dim = w.TwoDim(15.0, 300)
+    src = w.RandomPosGaussianSource(w.build_grid(dim), [[-10.0, -10.0]], [[-10.0, 10.0]], [0.3], [1.0], 1000.0,
+                                    rng=np.random.default_rng(5))
+    env = w.WaveEnv(dim, design_space=w.build_triple_ring_design_space(), source=src, integration_steps=30, actions=3,
+                    rng=np.random.default_rng(6), return_fields=False)
+    env.reset()
+    pol = w.RandomDesignPolicy(env.action_space(), np.random.default_rng(7))
+    env(pol(env))
+    s = env.state()
+    frames = env.ctx.get_frames()[:, :, 0, :]
+    full = np.concatenate([frames, env.ctx.source_shape()[:, :, None]], axis=2)
+    assert s.wave.shape == (128, 128, 4)
+    assert np.array_equal(s.wave, wo.imresize_linear(full, (128, 128)))
+    assert np.abs(s.wave[:, :, 2]).max() > 0
+    env.ctx.close()

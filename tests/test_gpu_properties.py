@@ -80,7 +80,7 @@ def test_signal_continuity_and_frames_across_actions():
         assert np.array_equal(ep.y[k][0], ep.y[k - 1][-1])           # row 1 of a step == last row of the previous
     assert ep.y[0].shape == (101, 3) and np.all(np.diff(ep.y[0][:, 1]) >= 0) is not None
     st = env.state()
-    assert st.wave.shape == (700, 700, 4)
+    assert st.wave.shape == (128, 128, 4)                           # env.resolution, resized on the device
     env.reset()
     assert env.time_step == 0 and not env.wave.any()
 

@@ -265,3 +265,39 @@ def test_pml_absorbs_a_pulse():
         _, es, _ = co.integrate(dim.x, dim.y, sx, sx, wo.WATER, 1e-5, st, ts, nthreads=4)
         left[scale] = es[-1, 0] / es[0, 0]
     assert left[20000.0] < 0.05 * left[0.0], left
+
+
+# ---- the observation path state(env) = imresize(cat(u_tot frames, source shape), resolution) ------
+def test_imresize_linear_restated_rule():
+    """imresize is Images.jl's (third-party, unpinned): PARITY UNPINNED.  What is pinned here is the rule as restated in
+    waves_oracle.imresize_linear: pixel-centre aligned linear interpolation, Float64 evaluation rounded once."""
+    f32 = np.float32
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((40, 30, 4)).astype(f32)
+    assert np.array_equal(wo.imresize_linear(a, (40, 30)), a)                     # same size: identity
+    c = np.full((50, 70, 2), 3.25, f32)
+    assert np.array_equal(wo.imresize_linear(c, (16, 9)), np.full((16, 9, 2), 3.25, f32))   # constants survive
+    # an affine field is reproduced exactly at the pixel-centre aligned sample positions
+    i, j = np.meshgrid(np.arange(1, 65), np.arange(1, 49), indexing="ij")
+    lin = (0.5 * i - 0.25 * j + 2.0).astype(f32)                                     # exactly representable
+    r = wo.imresize_linear(lin, (16, 12))
+    xo = (64 / 16) * (np.arange(1, 17) - 0.5) + 0.5
+    yo = (48 / 12) * (np.arange(1, 13) - 0.5) + 0.5
+    want = (0.5 * xo[:, None] - 0.25 * yo[None, :] + 2.0).astype(f32)
+    assert np.array_equal(r, want)
+    # 2:1 in both axes: the sample point is the centre of a 2x2 block -> its mean
+    b = rng.standard_normal((8, 6)).astype(f32)
+    m = wo.imresize_linear(b, (4, 3))
+    blk = b.astype(np.float64).reshape(4, 2, 3, 2)
+    want = (0.5 * (0.5 * blk[:, 0, :, 0] + 0.5 * blk[:, 1, :, 0]) + 0.5 * (0.5 * blk[:, 0, :, 1] + 0.5 * blk[:, 1, :, 1]))
+    assert np.array_equal(m, want.astype(f32))
+    # the env wires it up: (128, 128, 4) from three U_tot frames and the source shape
+    dim = wo.TwoDim.from_size(15.0, 160)
+    src = wo.RandomPosGaussianSource(wo.build_grid(dim), [[-10.0, -10.0]], [[-10.0, 10.0]], [0.3], [1.0], 1000.0)
+    env = wo.WaveEnv(dim, design_space=wo.build_triple_ring_design_space(), source=src, integration_steps=20, actions=2,
+                     rng=np.random.default_rng(0))
+    env.reset()
+    x = env.state()
+    assert x.shape == (128, 128, 4) and x.dtype == f32
+    assert np.array_equal(x[:, :, :3], np.zeros((128, 128, 3), f32))
+    assert np.array_equal(x[:, :, 3], wo.imresize_linear(src.shape, (128, 128))) and x[:, :, 3].max() > 0

@@ -87,6 +87,7 @@ def lib():
     _sig(L, "wv_set_source_shape", [ctx, _fp, C.c_float])
     _sig(L, "wv_set_gaussian_source", [ctx, C.c_int, _fp, _fp, _fp, C.c_float])
     _sig(L, "wv_get_source_shape", [ctx, _fp])
+    _sig(L, "wv_observation", [ctx, C.c_int, C.c_int, _fp])
     _sig(L, "wv_set_design", [ctx, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_float])
     _sig(L, "wv_speed_field", [ctx, C.c_float, _fp])
     _sig(L, "wv_source_field", [ctx, C.c_float, _fp])
@@ -237,6 +238,12 @@ class Context:
         for a in arrs:
             assert a.shape[0] == M
         self._ck(self._L.wv_set_design(self._h, M, *[fptr(a) for a in arrs], float(ti), float(tf)))
+
+    def observation(self, rx, ry):
+        """state(env)'s x: (rx, ry, 4) = imresize(cat(u_tot frames, source shape), (rx, ry)), resized on the device."""
+        o = np.empty((int(rx), int(ry), 4), np.float32, order="F")
+        self._ck(self._L.wv_observation(self._h, int(rx), int(ry), fptr(o)))
+        return o
 
     def speed_field(self, t):
         o = np.empty((self.nx, self.ny), np.float32, order="F")

@@ -53,6 +53,8 @@ struct wv_ctx {
     size_t traj_cap = 0;
     float *d_small = nullptr;  // gaussian parameters
     size_t small_cap = 0;
+    float *d_obs = nullptr;    // wv_observation output
+    size_t obs_cap = 0;
     float *d_sfac = nullptr;   // per-step source time factors [nsteps][3]
     size_t sfac_cap = 0;
     std::vector<FusedStep> fsteps;
@@ -222,7 +224,7 @@ int wv_destroy(wv_ctx *c)
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     float *bufs[] = {c->d_x, c->d_y, c->d_sx, c->d_sy, c->d_frames, c->d_scratch[0], c->d_scratch[1], c->d_yA, c->d_yB,
-                     c->d_acc, c->d_G, c->d_plane[0], c->d_plane[1], c->d_epart, c->d_signal, c->d_traj, c->d_small,
+                     c->d_acc, c->d_G, c->d_plane[0], c->d_plane[1], c->d_epart, c->d_signal, c->d_traj, c->d_small, c->d_obs,
                      c->d_elast, c->d_sfac};
     for (float *b : bufs)
         if (b) (void)hipFree(b);
@@ -461,6 +463,24 @@ int wv_get_source_shape(wv_ctx *c, float *shape)
     CHECK_CTX(c);
     if (!shape) return fail(c, WV_ERR_INVALID, "wv_get_source_shape: NULL");
     HIPCHK(c, hipMemcpyAsync(shape, c->d_G, c->P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WV_OK;
+}
+
+int wv_observation(wv_ctx *c, int rx, int ry, float *out)
+{
+    CHECK_CTX(c);
+    if (!out) return fail(c, WV_ERR_INVALID, "wv_observation: NULL");
+    if (rx < 1 || ry < 1 || rx > c->nx || ry > c->ny)
+        return fail(c, WV_ERR_INVALID, "wv_observation: resolution must be within 1 .. grid size (src/env.jl:52)");
+    if (c->pending) return fail(c, WV_ERR_STATE, "wv_observation: an integrate is pending");
+    const size_t n = (size_t)rx * ry * 4;
+    int rc = ensure(c, &c->d_obs, &c->obs_cap, n);
+    if (rc) return rc;
+    launch_observation(c->grid, frame(c, 0), frame(c, 1), frame(c, 2), c->has_source ? c->d_G : nullptr, rx, ry, c->d_obs,
+                       c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->d_obs, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return WV_OK;
 }

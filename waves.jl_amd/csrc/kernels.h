@@ -47,5 +47,8 @@ void launch_gaussian(const Grid &g, int K, const float *mu, const float *sigma, 
 void launch_scale(const float *in, float f, float *out, size_t n, hipStream_t s);
 void launch_gradient(const Grid &g, int axis, const float *u, float *out, hipStream_t s);
 void launch_copy_planes(const float *state, size_t P, float *tot, float *inc, hipStream_t s);
+// (rx, ry, 4) observation of state(env): U_tot of the three frames + the source shape (nullptr: zeros), resized
+void launch_observation(const Grid &g, const float *f0, const float *f1, const float *f2, const float *G, int rx, int ry,
+                        float *out, hipStream_t s);
 
 }  // namespace wv

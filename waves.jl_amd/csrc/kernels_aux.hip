@@ -123,6 +123,40 @@ __global__ __launch_bounds__(TPB) void k_copy_planes(const float *__restrict__ s
     }
 }
 
+// state(env): x = imresize(cat(env.wave[:, :, 1, :], env.source.shape, dims = 3), env.resolution)   src/env.jl:132-137.
+// imresize is Images.jl / ImageTransformations (third-party, version unpinned, absent here).  Its published rule,
+// restated: linear B-spline interpolation of the original (flat beyond the edge pixels), sampled pixel-centre aligned at
+// x_o = (n/r)*(i - 0.5) + 0.5 (1-based) per resized axis, evaluated in Float64 and rounded once to Float32; axes that
+// keep their size (the 4 channels) are copied.  The summation order is OUR definition (x inside, y outside): parity with
+// Julia is unpinned; the tests compare bit for bit with the same rule restated on the CPU.
+__global__ __launch_bounds__(TPB) void k_observation(const float *__restrict__ f0, const float *__restrict__ f1,
+                                                     const float *__restrict__ f2, const float *__restrict__ G, int nx,
+                                                     int ny, int rx, int ry, float *__restrict__ out)
+{
+    const size_t total = (size_t)rx * ry * 4;
+    const double sx = (double)nx / (double)rx, sy = (double)ny / (double)ry;
+    for (size_t q = (size_t)blockIdx.x * TPB + threadIdx.x; q < total; q += (size_t)gridDim.x * TPB) {
+        const int i = (int)(q % rx), j = (int)((q / rx) % ry), ch = (int)(q / ((size_t)rx * ry));
+        const float *src = ch == 0 ? f0 : (ch == 1 ? f1 : (ch == 2 ? f2 : G));
+        if (!src) {  // NoSource: the shape channel is zero
+            out[q] = 0.0f;
+            continue;
+        }
+        double xo = sx * ((double)(i + 1) - 0.5) + 0.5 - 1.0;  // 0-based coordinate in the original
+        double yo = sy * ((double)(j + 1) - 0.5) + 0.5 - 1.0;
+        xo = xo < 0.0 ? 0.0 : (xo > (double)(nx - 1) ? (double)(nx - 1) : xo);
+        yo = yo < 0.0 ? 0.0 : (yo > (double)(ny - 1) ? (double)(ny - 1) : yo);
+        const int i0 = (int)floor(xo), j0 = (int)floor(yo);
+        const int i1 = i0 + 1 < nx ? i0 + 1 : nx - 1, j1 = j0 + 1 < ny ? j0 + 1 : ny - 1;
+        const double fx = xo - (double)i0, fy = yo - (double)j0;
+        const double a00 = src[(size_t)j0 * nx + i0], a10 = src[(size_t)j0 * nx + i1];
+        const double a01 = src[(size_t)j1 * nx + i0], a11 = src[(size_t)j1 * nx + i1];
+        const double lo = (1.0 - fx) * a00 + fx * a10;
+        const double hi = (1.0 - fx) * a01 + fx * a11;
+        out[q] = (float)((1.0 - fy) * lo + fy * hi);
+    }
+}
+
 dim3 grid2d(const Grid &g) { return dim3((g.nx + 63) / 64, (g.ny + 3) / 4, 1); }
 int grid1d(size_t n) { size_t b = (n + TPB - 1) / TPB; return (int)(b > 2048 ? 2048 : (b ? b : 1)); }
 
@@ -156,6 +190,13 @@ void launch_scale(const float *in, float f, float *out, size_t n, hipStream_t s)
 void launch_gradient(const Grid &g, int axis, const float *u, float *out, hipStream_t s)
 {
     hipLaunchKernelGGL(k_gradient, grid2d(g), dim3(TPB), 0, s, g, axis, u, out);
+}
+
+void launch_observation(const Grid &g, const float *f0, const float *f1, const float *f2, const float *G, int rx, int ry,
+                        float *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_observation, dim3(grid1d((size_t)rx * ry * 4)), dim3(TPB), 0, s, f0, f1, f2, G, g.nx, g.ny, rx, ry,
+                       out);
 }
 
 void launch_copy_planes(const float *state, size_t P, float *tot, float *inc, hipStream_t s)

@@ -105,11 +105,10 @@ class WaveEnv:
         return tspan, interp, u_tot, u_inc
 
     def state(self):
-        """RLBase.state  src/env.jl:132-137 WITHOUT the imresize (Images.jl's interpolation is third-party and
-        unpinned: SURVEY 8f rank 1, a "next" row).  Returns the three U_tot frames + source shape at full resolution."""
-        w = self.ctx.get_frames()[:, :, 0, :]
-        shape = self.ctx.source_shape()
-        x = np.concatenate([w, shape[:, :, None]], axis=2)
+        """RLBase.state  src/env.jl:132-137: the three U_tot frames and the source shape, `imresize`d to
+        `env.resolution` -- on the device (wv_observation; 3 x 64 KB leave the GPU instead of 7.8 MB).  imresize is
+        Images.jl's (third-party, unpinned): the rule implemented is stated in csrc/kernels_aux.hip (k_observation)."""
+        x = self.ctx.observation(*self.resolution)
         return WaveEnvState(self.dim, self.build_tspan(), x, self.design)
 
     def action_space(self):
