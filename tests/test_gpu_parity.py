@@ -515,3 +515,27 @@ def test_env_state_is_the_resized_observation():
     assert np.array_equal(s.wave, wo.imresize_linear(full, (128, 128)))
     assert np.abs(s.wave[:, :, 2]).max() > 0
     env.ctx.close()
+
+
+def test_episode_with_observations_windowing_and_file_round_trip(tmp_path):
+    """SURVEY 8f ranks 1-2 end to end on the device: generate_episode! recording state(env) before every action
+    (src/data.jl:12-33), prepare_data (:35-57), save / load."""
+    dim = w.TwoDim(15.0, 160)
+    src = w.RandomPosGaussianSource(w.build_grid(dim), [[-10.0, -10.0]], [[-10.0, 10.0]], [0.3], [1.0], 1000.0,
+                                    rng=np.random.default_rng(15))
+    env = w.WaveEnv(dim, design_space=w.build_triple_ring_design_space(), source=src, integration_steps=20, actions=4,
+                    rng=np.random.default_rng(16), return_fields=False)
+    pol = w.RandomDesignPolicy(env.action_space(), np.random.default_rng(17))
+    ep = w.generate_episode(pol, env, with_states=True)
+    assert len(ep) == 4 and len(ep.s) == 4 and ep.s[0].wave.shape == (128, 128, 4)
+    assert not ep.s[0].wave[:, :, :3].any() and ep.s[0].wave[:, :, 3].max() > 0      # zero wave, source shape present
+    assert np.abs(ep.s[3].wave[:, :, 2]).max() > 0
+    s, a, t, y = w.prepare_data(ep, 2)
+    assert len(y) == 3 and y[0].shape == (41, 3) and t[0].shape == (41,)
+    assert np.array_equal(y[1][:21], ep.y[1]) and np.array_equal(y[1][21:], ep.y[2][1:])
+    p = str(tmp_path / "ep.npz")
+    ep.save(p)
+    back = w.Episode.load(p)
+    assert all(np.array_equal(b.wave, e.wave) for b, e in zip(back.s, ep.s))
+    assert all(np.array_equal(b, e) for b, e in zip(back.y, ep.y))
+    env.ctx.close()

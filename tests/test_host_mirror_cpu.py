@@ -73,3 +73,73 @@ def test_oracle_to_mirror_roundtrip():
     os_ = wo.build_triple_ring_design_space()
     m = oracle_to_mirror_design(w, os_.low)
     assert isinstance(m, w.Cloak) and _eq(m, os_.low)
+
+
+# ---- Episode container, prepare_data windowing, on-disk episode format (src/data.jl, src/utils.jl) ----
+def _toy_episode(A=5, n=6, with_states=True):
+    rng = np.random.default_rng(11)
+    ds = w.build_triple_ring_design_space()
+    dim = w.TwoDim(15.0, 16)
+    s, a, t, y = [], [], [], []
+    t0 = 0.0
+    design = w.rand(ds, rng)
+    for k in range(A):
+        ts = (t0 + 1e-5 * np.arange(n)).astype(np.float32)
+        if with_states:
+            s.append(w.env.WaveEnvState(dim, ts, np.asfortranarray(rng.standard_normal((8, 8, 4)).astype(np.float32)), design))
+        a.append(w.rand(w.build_action_space(design, 0.25), rng))
+        t.append(ts)
+        sig = rng.standard_normal((n, 3)).astype(np.float32)
+        if y:
+            sig[0] = y[-1][-1]          # row 1 of a step equals the last row of the previous step (src/env.jl:105-111)
+        y.append(sig)
+        t0 = float(ts[-1])
+    return w.Episode(s, a, t, y)
+
+
+def test_flatten_repeated_last_dim_follows_the_reference():
+    """src/utils.jl:20-35: first segment whole, later segments without their (repeated) first sample, segment-major."""
+    x = np.arange(2 * 4 * 3, dtype=np.float32).reshape(2, 4, 3)          # (rows, n = 4 samples, k = 3 segments)
+    got = w.flatten_repeated_last_dim(x)
+    want = np.stack([np.concatenate([x[r, :, 0], x[r, 1:, 1], x[r, 1:, 2]]) for r in range(2)])
+    assert got.shape == (2, 4 + 3 * 2) and np.array_equal(got, want)
+    v = np.stack([np.array([0, 1, 2, 3], np.float32), np.array([3, 4, 5, 6], np.float32)], axis=1)   # hcat of two tspans
+    assert np.array_equal(w.flatten_repeated_last_dim(v), np.arange(7, dtype=np.float32))
+    both = w.flatten_repeated_last_dim([x[0], x[1]])                       # Vector{<:AbstractMatrix} method: hcat
+    assert both.shape == (10, 2) and np.array_equal(both[:, 1], want[1])
+
+
+def test_prepare_data_windows_like_the_reference():
+    ep = _toy_episode(A=5, n=6)
+    s, a, t, y = w.prepare_data(ep, 3)
+    assert len(s) == len(a) == len(t) == len(y) == 3                       # length(ep) - (horizon - 1)
+    for i in range(3):
+        assert s[i] is ep.s[i] and a[i] == list(ep.a[i:i + 3])
+        assert t[i].shape == (6 + 5 * 2,) and y[i].shape == (6 + 5 * 2, 3)
+        assert np.array_equal(t[i], np.concatenate([ep.t[i], ep.t[i + 1][1:], ep.t[i + 2][1:]]))
+        assert np.array_equal(y[i], np.concatenate([ep.y[i], ep.y[i + 1][1:], ep.y[i + 2][1:]]))
+        assert np.all(np.diff(t[i]) > 0)                                    # no repeated boundary sample left
+    s2, a2, t2, y2 = w.prepare_data([ep, ep], 3)                            # vcat over episodes (src/data.jl:59-62)
+    assert len(y2) == 6 and np.array_equal(y2[3], y[0])
+    assert w.prepare_data(ep, 1)[3][0].shape == (6, 3)
+
+
+def test_episode_file_round_trip_without_pickle(tmp_path):
+    ep = _toy_episode(A=4, n=5)
+    p = str(tmp_path / "episode.npz")
+    ep.save(p)
+    z = np.load(p, allow_pickle=False)                                      # plain arrays + a JSON manifest only
+    assert z["y"].shape == (4, 5, 3) and z["s_wave"].shape == (4, 8, 8, 4)
+    back = w.Episode.load(p)
+    assert len(back) == 4
+    for k in range(4):
+        assert np.array_equal(back.y[k], ep.y[k]) and np.array_equal(back.t[k], ep.t[k])
+        assert np.array_equal(back.s[k].wave, ep.s[k].wave) and np.array_equal(back.s[k].tspan, ep.s[k].tspan)
+        for d0, d1 in ((back.a[k], ep.a[k]), (back.s[k].design, ep.s[k].design)):
+            assert type(d0) is type(d1)
+            c0, c1 = d0.stacked(), d1.stacked()
+            assert np.array_equal(c0.pos, c1.pos) and np.array_equal(c0.r, c1.r) and np.array_equal(c0.c, c1.c)
+    assert np.array_equal(back.s[0].dim.x, ep.s[0].dim.x)
+    bare = _toy_episode(A=2, n=5, with_states=False)
+    bare.save(p)
+    assert w.Episode.load(p).s == [] and len(w.Episode.load(p)) == 2

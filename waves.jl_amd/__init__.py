@@ -5,7 +5,8 @@ The directory is called `waves.jl_amd`; import it as `waves_jl_amd` (see waves_j
 """
 from . import _ffi
 from ._ffi import WavesAmdError, build, device_count
-from .data import Episode, generate_episode
+from .data import (Episode, design_from_dict, design_to_dict, flatten_repeated_last_dim, generate_episode,
+                   prepare_data)
 from .designs import (AIR, ALUMINIUM, BRASS, COPPER, WATER, AdjustablePositionScatterers, AdjustableRadiiScatterers, Cloak,
                       Cylinders, DesignInterpolator, DesignSpace, NoDesign, build_action_space,
                       build_radii_design_space, build_simple_radii_design_space, build_triple_ring_design_space, rand,
