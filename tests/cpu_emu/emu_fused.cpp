@@ -295,6 +295,7 @@ static int run_case(const Case &cs)
     p.tiles = pl.tiles.data(); p.cyl_idx = idx.data();
     std::vector<unsigned long long> xch(cs.resident ? (size_t)2 * 12 * P : 1, 0ull);
     p.xch = xch.data();
+    p.xch_bytes = (unsigned)(xch.size() * sizeof(unsigned long long));
     p.tag_base = 4094;  // arbitrary; even + odd tags both occur
     p.reduced = cs.aux == 0;
     const int key = cs.NW * 1000 + cs.RF * 100 + cs.RB * 10 + cs.RP;

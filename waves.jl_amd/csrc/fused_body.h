@@ -90,7 +90,8 @@ struct FusedParams {
     // k_steps_resident: all steps of the call in one launch, every tile resident for the whole call
     const StepIO *steps;       // [nsteps]; steps[s].u == steps[s-1].out
     int nsteps;
-    unsigned long long *xch;   // halo exchange: [2 parities][12 planes][P] words of (tag << 32 | value bits)
+    unsigned long long *xch;   // halo exchange: [2 parities][6 fields][P cells][2 sets] words of (tag << 32 | value bits)
+    unsigned xch_bytes;        // its size
     unsigned tag_base;         // the border cells of step s carry the tag tag_base + s + 1
     int *abort;                // set when a wait gave up: every tile then leaves the kernel
     int reduced;               // the tiles use reduced field sets (auxiliary fields are zero outside the PML)
@@ -377,20 +378,6 @@ WV_HD unsigned xch_copy(unsigned v)
     return v;
 #endif
 }
-WV_HD unsigned long long xch_pack(float v, unsigned tag)
-{
-    return ((unsigned long long)tag << 32) | (unsigned long long)xch_copy(__builtin_bit_cast(unsigned, v));
-}
-// word at byte offset `off` of a plane: a block-uniform 64-bit base plus a 32-bit per-lane offset (one VGPR per row
-// instead of an address pair per word -- the poll loop keeps all of a thread's halo words in flight at once)
-WV_HD unsigned long long *xch_word(unsigned long long *plane, unsigned off)
-{
-    return reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(plane) + off);
-}
-WV_HD const unsigned long long *xch_word(const unsigned long long *plane, unsigned off)
-{
-    return reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(plane) + off);
-}
 // keeps the compiler from hoisting the per-word address arithmetic out of the poll loop (24 address pairs kept live
 // across it) -- formed next to the load it folds into the instruction's scalar-base + 32-bit-offset addressing
 WV_HD unsigned xch_opaque(unsigned off)
@@ -400,20 +387,45 @@ WV_HD unsigned xch_opaque(unsigned off)
 #endif
     return off;
 }
-WV_HD void xch_put(unsigned long long *ptr, unsigned long long w)
-{
+// The two words of a cell and field -- total and incident wave set -- are adjacent in memory and move together as ONE
+// 16-byte access (half the memory instructions, and the four border cells of a row become one full 64-byte line).
+// Each 8-byte half is still a self-validating (tag, value) word, so nothing depends on the 16 bytes arriving together.
+// Layout: [tag parity (2)][field of a set (6)][cell (P)][wave set (2)] 8-byte words.
+struct XchPair {
+    unsigned v0, t0, v1, t1;  // total: (value bits, tag), incident: (value bits, tag)
+};
 #if defined(__HIP_DEVICE_COMPILE__)
-    __hip_atomic_store(ptr, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+typedef unsigned int wv_u4 __attribute__((ext_vector_type(4)));
+// raw buffer resource over the exchange buffer (gfx9 word 3: 32-bit data format, raw addressing); accesses carry the
+// agent-scope (sc1) cache policy: stores write through to memory, loads are served from there
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t xch_rsrc(const FusedParams &p)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(p.xch, 0, (int)p.xch_bytes, 0x00020000);
+}
+#endif
+// byte offset of the plane of field `pl` (0..5) in the buffer of tag parity `par` (block-uniform)
+WV_HD unsigned xch_plane_offset(const FusedParams &p, unsigned par, int pl) { return (par * 6u + (unsigned)pl) * (p.P * 16u); }
+WV_HD void xch_put_pair(const FusedParams &p, unsigned plane_off, unsigned cell_off, float vt, float vi, unsigned tag)
+{
+    const unsigned b0 = xch_copy(__builtin_bit_cast(unsigned, vt)), b1 = xch_copy(__builtin_bit_cast(unsigned, vi));
+#if defined(__HIP_DEVICE_COMPILE__)
+    const wv_u4 w = {b0, tag, b1, tag};
+    __builtin_amdgcn_raw_buffer_store_b128(w, xch_rsrc(p), (int)cell_off, (int)plane_off, 16);  // aux 16: sc1
 #else
-    *ptr = w;
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(p.xch) + plane_off + cell_off);
+    q[0] = ((unsigned long long)tag << 32) | b0;
+    q[1] = ((unsigned long long)tag << 32) | b1;
 #endif
 }
-WV_HD unsigned long long xch_get(const unsigned long long *ptr)
+WV_HD XchPair xch_get_pair(const FusedParams &p, unsigned plane_off, unsigned cell_off)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const wv_u4 w = __builtin_amdgcn_raw_buffer_load_b128(xch_rsrc(p), (int)cell_off, (int)plane_off, 16);
+    return XchPair{w.x, w.y, w.z, w.w};
 #else
-    return *ptr;
+    const unsigned long long *q =
+        reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(p.xch) + plane_off + cell_off);
+    return XchPair{(unsigned)q[0], (unsigned)(q[0] >> 32), (unsigned)q[1], (unsigned)(q[1] >> 32)};
 #endif
 }
 
@@ -445,22 +457,22 @@ WV_HD void fused_xch_store(const FusedParams &p, unsigned tag, const TileDesc &t
     if (lane < FT_H || lane >= FT_H + t.ox) return;
     const bool ringx = lane < 2 * FT_H || lane >= t.ox;
     const int gx = t.x0 - FT_H + lane;
-    unsigned long long *base = p.xch + (size_t)(tag & 1u) * 12 * p.P;
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
         const int ly = w + NW * rr;
         if (ly < FT_H || ly >= FT_H + t.oy) continue;
         if (!(ringx || ly < 2 * FT_H || ly >= t.oy)) continue;
-        const int gy = t.y0 - FT_H + ly;
-        const unsigned off = ((unsigned)gy * (unsigned)p.nx + (unsigned)gx) * 8u;  // byte offset: 8*P < 2^32
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int j = 0; j < NS; ++j) {
-#ifndef WV_XCH_NOSTORE  // (timing experiment only)
-                xch_put(xch_word(base + (size_t)(6 * s + aux_plane(AUX, j)) * p.P, off), xch_pack(r.y[rr][s][j], tag));
+#ifdef WV_XCH_NOXBORDER  // (timing experiment only: rows that only contribute their x-border are not sent)
+        if (!(ly < 2 * FT_H || ly >= t.oy)) continue;
 #endif
-            }
+        const int gy = t.y0 - FT_H + ly;
+        const unsigned off = ((unsigned)gy * (unsigned)p.nx + (unsigned)gx) * 16u;  // byte offset in a plane: 16*P < 2^32
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+#ifndef WV_XCH_NOSTORE  // (timing experiment only)
+            xch_put_pair(p, xch_plane_offset(p, tag & 1u, aux_plane(AUX, j)), off, r.y[rr][0][j], r.y[rr][1][j], tag);
+#endif
+        }
     }
 }
 
@@ -476,7 +488,6 @@ WV_HD bool fused_xch_load(const FusedParams &p, unsigned tag, const TileDesc &t,
     const bool inx = gx >= 0 && gx < p.nx && lane < t.ox + 2 * FT_H;  // (columns beyond the region belong to nobody's ring)
     const int cgx = gx < 0 ? 0 : (gx >= p.nx ? p.nx - 1 : gx);
     const bool ownx = lane >= FT_H && lane < FT_H + t.ox;
-    const unsigned long long *base = p.xch + (size_t)(tag & 1u) * 12 * p.P;
     bool ok = true;
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
@@ -484,7 +495,7 @@ WV_HD bool fused_xch_load(const FusedParams &p, unsigned tag, const TileDesc &t,
         const int gy = t.y0 - FT_H + ly;
         const bool in = inx && gy >= 0 && gy < p.ny && ly < t.oy + 2 * FT_H;
         const int cgy = gy < 0 ? 0 : (gy >= p.ny ? p.ny - 1 : gy);
-        const unsigned off = ((unsigned)cgy * (unsigned)p.nx + (unsigned)cgx) * 8u;
+        const unsigned off = ((unsigned)cgy * (unsigned)p.nx + (unsigned)cgx) * 16u;
         const bool own = ownx && ly >= FT_H && ly < FT_H + t.oy;
         const bool need = in && !own;
         // With reduced field sets the owner of a halo cell carries -- and sends -- an auxiliary field only where that
@@ -501,36 +512,32 @@ WV_HD bool fused_xch_load(const FusedParams &p, unsigned tag, const TileDesc &t,
             }
             needj[j] = need && live;
         }
-        unsigned long long wd[2][NS];
+        XchPair wd[NS];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int j = 0; j < NS; ++j) wd[s][j] = 0;
-        if (need) {  // one divergent region per row; the word addresses are formed right here (uniform base + offset)
+        for (int j = 0; j < NS; ++j) wd[j] = XchPair{0u, 0u, 0u, 0u};
+        if (need) {  // one divergent region per row; the offsets are formed right here (uniform base + 32-bit offset)
             const unsigned o = xch_opaque(off);
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int j = 0; j < NS; ++j)
-                    if (needj[j]) wd[s][j] = xch_get(xch_word(base + (size_t)(6 * s + aux_plane(AUX, j)) * p.P, o));
+            for (int j = 0; j < NS; ++j)
+                if (needj[j]) wd[j] = xch_get_pair(p, xch_plane_offset(p, tag & 1u, aux_plane(AUX, j)), o);
         }
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                float v = own ? r.y[rr][s][j] : 0.0f;
-                if (needj[j]) {
+        for (int j = 0; j < NS; ++j) {
+            float vt = own ? r.y[rr][0][j] : 0.0f, vi = own ? r.y[rr][1][j] : 0.0f;
+            if (needj[j]) {
 #ifdef WV_XCH_DEBUG
-                    if ((unsigned)(wd[s][j] >> 32) != tag && wv_xch_debug)
-                        printf("  slot %d aux %d x0 %d y0 %d ox %d oy %d: lane %d ly %d gx %d gy %d plane %d set %d has tag %u want %u\n", t.slot, t.aux, t.x0, t.y0, t.ox, t.oy, lane, ly, gx, gy, aux_plane(AUX, j), s, (unsigned)(wd[s][j] >> 32), tag), wv_xch_debug--;
+                if ((wd[j].t0 != tag || wd[j].t1 != tag) && wv_xch_debug)
+                    printf("  slot %d aux %d x0 %d y0 %d ox %d oy %d: lane %d ly %d gx %d gy %d plane %d has tags %u %u want %u\n", t.slot, t.aux, t.x0, t.y0, t.ox, t.oy, lane, ly, gx, gy, aux_plane(AUX, j), wd[j].t0, wd[j].t1, tag), wv_xch_debug--;
 #endif
 #ifndef WV_XCH_NOWAIT  // (timing experiment only: results are wrong without the check)
-                    ok = ok && (unsigned)(wd[s][j] >> 32) == tag;
+                ok = ok && wd[j].t0 == tag && wd[j].t1 == tag;
 #endif
-                    v = __builtin_bit_cast(float, xch_copy((unsigned)wd[s][j]));
-                }
-                r.u[rr][s][j] = v;
+                vt = __builtin_bit_cast(float, xch_copy(wd[j].v0));
+                vi = __builtin_bit_cast(float, xch_copy(wd[j].v1));
             }
+            r.u[rr][0][j] = vt;
+            r.u[rr][1][j] = vi;
+        }
     }
     return ok;
 }

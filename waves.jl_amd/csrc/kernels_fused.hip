@@ -627,6 +627,7 @@ static FusedParams make_params(FusedPlan *pl, const FusedCall &call, int step, c
     p.steps = nullptr;
     p.nsteps = 0;
     p.xch = nullptr;
+    p.xch_bytes = 0;
     p.tag_base = 0;
     p.reduced = 0;
     p.poll_delay = 0;
@@ -741,6 +742,7 @@ int fused_try_resident(FusedPlan *pl, const FusedCall &call, const FusedStep *st
     p.steps = pl->d_steps;
     p.nsteps = nsteps;
     p.xch = pl->d_xch;
+    p.xch_bytes = (unsigned)(xwords * sizeof(unsigned long long));
     p.tag_base = pl->tag_base;
     p.reduced = pl->tiles_aux_zero ? 1 : 0;
     static const int poll_delay = getenv("WAVES_AMD_POLL_DELAY") ? atoi(getenv("WAVES_AMD_POLL_DELAY")) : 0;
