@@ -175,10 +175,14 @@ def main():
     t0 = time.perf_counter()
     sigs = []
     dev_ms = 0.0
+    kern_ms, kern_launches = 0.0, 0
     for _ in range(args.steps):
         env(policy(env))
         sigs.append(env.signal)
-        dev_ms += env.ctx.timing()["total_ms"]
+        tim_ = env.ctx.timing()
+        dev_ms += tim_["total_ms"]
+        kern_ms += tim_["step_kernel_ms"]
+        kern_launches += tim_["step_kernel_launches"]
     all_sig = wd.gather_signals(np.stack(sigs))
     torch.cuda.synchronize()
     wd.barrier()
@@ -192,10 +196,10 @@ def main():
     # records on the ctx's stream around every wv_integrate call of the TIMED region above (first enqueue -> last kernel),
     # divided by the number of integrator launches in it:
     #   * resident path (the default whenever all tiles fit the device at once, e.g. 700^2): ONE launch of
-    #     k_steps_resident per action does all 100 steps, so a launch processes 100 x cells cell-updates; the bracket
-    #     also holds the ~100 KB table upload and two tiny reduction kernels (~2 % of it) -- the figure is conservative;
-    #   * single-step path (larger grids): 100 back-to-back k_step_fused launches per action, gaps included; agrees with
-    #     the rocprofv3 kernel-trace average to ~2 %.
+    #     k_steps_resident per action does all 100 steps, so a launch processes 100 x cells cell-updates; the events sit
+    #     directly around that launch;
+    #   * single-step path (larger grids): 100 back-to-back k_step_fused launches per action between one pair of events,
+    #     gaps included; agrees with the rocprofv3 kernel-trace average to ~2 %.
     # The event pair(s) placed directly around the integrator launch(es) (profiling mode) are reported for reference.
     out = None
     if rank == 0:
@@ -203,7 +207,10 @@ def main():
         impl = tim["impl"]
         resident = bool(tim.get("resident"))
         launches_per_action = 1 if resident else STEPS_PER_ACTION * (4 if impl == "staged" else 1)
-        avg_ms = dev_ms / (args.steps * launches_per_action)
+        if kern_launches > 0 and kern_ms > 0.0:   # fused path: events directly around the integrator launch(es)
+            avg_ms = kern_ms / kern_launches
+        else:                                      # staged path: whole call / launches
+            avg_ms = dev_ms / (args.steps * launches_per_action)
         env.ctx.set_profiling(True)
         kms, launches = 0.0, 0
         for _ in range(2):

@@ -73,7 +73,9 @@ typedef struct wv_config {
 /* timing of the last wv_integrate on this ctx, measured with HIP events on the ctx's stream */
 typedef struct wv_timing {
     double total_ms;        /* first enqueue -> last kernel of the call */
-    double step_kernel_ms;  /* sum of the durations of the per-step integrator kernels (profiling mode only, else 0) */
+    double step_kernel_ms;  /* duration of the integrator launch(es): fused path, the events around the resident launch
+                             * or the whole chain of single-step launches; profiling mode: the sum of the per-launch
+                             * brackets; staged path without profiling: 0 */
     int step_kernel_launches;
     int steps;
     int impl;               /* implementation that ran */

@@ -59,6 +59,7 @@ struct wv_ctx {
     size_t sfac_cap = 0;
     std::vector<FusedStep> fsteps;
     bool counted = false;  // this ctx is included in g_live_ctx
+    bool bracketed = false;  // kev[0] / kev[1] bracket the fused launch(es) of the pending call
     int prof_launches = 0, prof_events = 0;  // profiling mode: integrator launches / event pairs of the last call
     float *d_elast = nullptr;  // per-block energy partials of the state the last integrate ended on
     size_t elast_cap = 0;
@@ -675,8 +676,9 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
         rc = ensure(c, &c->d_traj, &c->traj_cap, (size_t)2 * (nsteps + 1) * c->P);
         if (rc) return rc;
     }
-    if (c->profiling) {
-        while (c->kev.size() < 2 * (size_t)nsteps) {
+    {  // one pair of events always (it brackets the fused launch(es) of the call), one pair per step when profiling
+        const size_t want = c->profiling ? 2 * (size_t)nsteps : 2;
+        while (c->kev.size() < want) {
             hipEvent_t ev;
             HIPCHK(c, hipEventCreate(&ev));
             c->kev.push_back(ev);
@@ -759,9 +761,15 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     c->prof_launches = nsteps * (impl == WV_IMPL_STAGED ? 4 : 1);
     c->prof_events = nsteps;
     bool resident = false;
+    c->bracketed = false;
     if (impl == WV_IMPL_FUSED && !c->profiling) {
+        // the integrator launch(es) of the call between two events: for the resident path that is exactly the one kernel
+        HIPCHK(c, hipEventRecord(c->kev[0], st));
         if (fused_run(c->fused, fcall, c->fsteps.data(), (int)c->fsteps.size(), st) != 0)
             return fail(c, WV_ERR_HIP, std::string("fused_run failed: ") + hipGetErrorString(hipGetLastError()));
+        HIPCHK(c, hipEventRecord(c->kev[1], st));
+        c->bracketed = true;
+        if (fused_last_resident(c->fused)) c->prof_launches = 1;
     } else if (impl == WV_IMPL_FUSED) {
         // profiling: the single resident launch bracketed by one pair of events, else every step by its own pair
         // (the events recorded inside the loop above are re-recorded here in stream order)
@@ -827,6 +835,12 @@ int wv_integrate_end(wv_ctx *c, float *signal, float *u_tot, float *u_inc)
         return fail(c, WV_ERR_HIP, "wv_integrate: the resident step kernel gave up waiting for a neighbouring tile "
                                    "(device shared with another cooperative kernel?); the state is invalid -- "
                                    "wv_reset / wv_set_state, or WAVES_AMD_FUSED_RESIDENT=0");
+    if (c->bracketed) {
+        float k = 0.0f;
+        HIPCHK(c, hipEventElapsedTime(&k, c->kev[0], c->kev[1]));
+        c->timing.step_kernel_ms = k;
+        c->timing.step_kernel_launches = c->prof_launches;
+    }
     if (c->profiling) {
         double sum = 0.0;
         for (int s = 0; s < c->prof_events; ++s) {
