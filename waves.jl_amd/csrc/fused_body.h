@@ -95,7 +95,6 @@ struct FusedParams {
     unsigned tag_base;         // the border cells of step s carry the tag tag_base + s + 1
     int *abort;                // set when a wait gave up: every tile then leaves the kernel
     int reduced;               // the tiles use reduced field sets (auxiliary fields are zero outside the PML)
-    int poll_delay;            // tuning: idle time before the first halo poll of a step, in units of 64 clocks
     int max_polls;             // a wave gives up (and the launch drains) after this many polls of one halo
     unsigned long long *stamps;  // diagnostic: [ntiles][16] shader-clock stamps per phase, or nullptr (normal runs)
 };

@@ -252,7 +252,6 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
         // halo of the next step: every wave polls the words of its own rows
         // (the next step's cylinders travel while the halo is awaited)
         const Cyl nc = fused_cyl_fetch<AUX, FL, RPT>(p, io.step + 1, t, tid, cx, r);
-        for (int d = 0; d < p.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
         bool ok = false;
         int polls = 0;
         for (; polls < p.max_polls; ++polls) {
@@ -630,7 +629,6 @@ static FusedParams make_params(FusedPlan *pl, const FusedCall &call, int step, c
     p.xch_bytes = 0;
     p.tag_base = 0;
     p.reduced = 0;
-    p.poll_delay = 0;
     p.max_polls = 0;
     p.abort = nullptr;
     p.stamps = nullptr;
@@ -745,8 +743,6 @@ int fused_try_resident(FusedPlan *pl, const FusedCall &call, const FusedStep *st
     p.xch_bytes = (unsigned)(xwords * sizeof(unsigned long long));
     p.tag_base = pl->tag_base;
     p.reduced = pl->tiles_aux_zero ? 1 : 0;
-    static const int poll_delay = getenv("WAVES_AMD_POLL_DELAY") ? atoi(getenv("WAVES_AMD_POLL_DELAY")) : 0;
-    p.poll_delay = poll_delay;
     const char *mp = getenv("WAVES_AMD_WAIT_POLLS");  // diagnostic, read per call (tests force a give-up with it)
     p.max_polls = (mp && atoi(mp) > 0) ? atoi(mp) : pl->max_polls;
     p.abort = pl->d_abort;
