@@ -184,8 +184,11 @@ class Cloak(AbstractDesign):
     def clamp(self, low, high):  # :226
         return Cloak(self.config.clamp(low.config, high.config), self.core.clamp(low.core, high.core))
 
-    def stacked(self):  # :228
-        return stack(self.config.cylinders, self.core)
+    def stacked(self):  # :228  (designs are immutable values: the stacked form is built once per object)
+        st = getattr(self, "_stacked", None)
+        if st is None:
+            st = self._stacked = stack(self.config.cylinders, self.core)
+        return st
 
     def __repr__(self):
         return f"Cloak({self.config!r}, core={self.core!r})"
