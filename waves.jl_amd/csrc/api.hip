@@ -833,8 +833,8 @@ int wv_integrate_end(wv_ctx *c, float *signal, float *u_tot, float *u_inc)
     c->timing.total_ms = ms;
     if (c->timing.impl == WV_IMPL_FUSED && fused_finish(c->fused, st) != 0)
         return fail(c, WV_ERR_HIP, "wv_integrate: the resident step kernel gave up waiting for a neighbouring tile "
-                                   "(device shared with another cooperative kernel?); the state is invalid -- "
-                                   "wv_reset / wv_set_state, or WAVES_AMD_FUSED_RESIDENT=0");
+                                   "(device shared with another process?); the state is invalid: wv_reset / wv_set_state.  "
+                                   "This context uses the single-step kernels from now on");
     if (c->bracketed) {
         float k = 0.0f;
         HIPCHK(c, hipEventElapsedTime(&k, c->kev[0], c->kev[1]));

@@ -764,9 +764,12 @@ int fused_finish(FusedPlan *pl, hipStream_t s)
     if (!pl->abort_pending) return 0;
     pl->abort_pending = false;
     if (*pl->h_abort == 0) return 0;
-    // a tile gave up waiting: the state is garbage.  Reset the protocol so that the context stays usable.
+    // a tile gave up waiting: the state is garbage.  Reset the protocol so that the context stays usable, and keep this
+    // context on the single-step kernels from now on: whatever kept a tile from running (another process's kernels on
+    // the same device, most likely) may well still be there at the next call.
     *pl->h_abort = 0;
     (void)hipMemsetAsync(pl->d_abort, 0, sizeof(int), s);
+    pl->use_resident = false;
     return 1;
 }
 
