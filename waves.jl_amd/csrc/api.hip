@@ -48,6 +48,8 @@ struct wv_ctx {
     float *d_epart = nullptr;
     size_t epart_cap = 0;
     float *d_signal = nullptr;
+    float *h_signal = nullptr;   // pinned: the energy trace is copied here inside the call's stream work
+    size_t h_signal_cap = 0;
     size_t signal_cap = 0;
     float *d_traj = nullptr;
     size_t traj_cap = 0;
@@ -230,6 +232,7 @@ int wv_destroy(wv_ctx *c)
     for (float *b : bufs)
         if (b) (void)hipFree(b);
     if (c->d_cyl) (void)hipFree(c->d_cyl);
+    if (c->h_signal) (void)hipHostFree(c->h_signal);
     if (c->fused) fused_destroy(c->fused);
     for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -793,6 +796,17 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     HIPCHK(c, hipGetLastError());
     if (want_signal) {
         launch_energy_final(c->d_epart, nsteps + 1, nblocks, c->dOmega, c->d_signal, st);
+        // the trace goes to pinned host memory as part of the call: wv_integrate_end then only waits for an event
+        // (polling it: the wake-up of a blocking wait costs more than the copy) and copies 1.2 KB host to host
+        const size_t ns = (size_t)(nsteps + 1) * 3;
+        if (ns > c->h_signal_cap) {
+            if (c->h_signal) (void)hipHostFree(c->h_signal);
+            c->h_signal = nullptr;
+            c->h_signal_cap = 0;
+            HIPCHK(c, hipHostMalloc((void **)&c->h_signal, ns * sizeof(float), hipHostMallocDefault));
+            c->h_signal_cap = ns;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->h_signal, c->d_signal, ns * sizeof(float), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipMemcpyAsync(c->d_elast, c->d_epart + (size_t)nsteps * nblocks * 3, (size_t)nblocks * 3 * sizeof(float),
                                  hipMemcpyDeviceToDevice, st));
     }
@@ -821,12 +835,35 @@ int wv_integrate_end(wv_ctx *c, float *signal, float *u_tot, float *u_inc)
     if (signal && !c->pend_signal) return fail(c, WV_ERR_STATE, "wv_integrate_end: signal was not requested in _begin");
     if ((u_tot || u_inc) && !c->pend_fields) return fail(c, WV_ERR_STATE, "wv_integrate_end: fields were not requested in _begin");
     hipStream_t st = c->stream;
-    if (signal) HIPCHK(c, hipMemcpyAsync(signal, c->d_signal, (size_t)(n + 1) * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
     if (u_tot) HIPCHK(c, hipMemcpyAsync(u_tot, c->d_traj, (size_t)(n + 1) * c->P * sizeof(float), hipMemcpyDeviceToHost, st));
     if (u_inc)
         HIPCHK(c, hipMemcpyAsync(u_inc, c->d_traj + (size_t)(n + 1) * c->P, (size_t)(n + 1) * c->P * sizeof(float),
                                  hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    if (!u_tot && !u_inc) {
+        // everything the caller gets is already on its way (or here): poll the call's last event for a while before
+        // falling back to a blocking wait
+        static const bool spin = !(getenv("WAVES_AMD_SPIN") && atoi(getenv("WAVES_AMD_SPIN")) == 0);
+        bool done = false;
+        if (spin) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (;;) {
+                const hipError_t q = hipEventQuery(c->ev1);
+                if (q == hipSuccess) {
+                    done = true;
+                    break;
+                }
+                if (q != hipErrorNotReady) {
+                    (void)hipGetLastError();
+                    break;
+                }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+            }
+        }
+        if (!done) HIPCHK(c, hipStreamSynchronize(st));
+    } else {
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
+    if (signal) memcpy(signal, c->h_signal, (size_t)(n + 1) * 3 * sizeof(float));
     if (c->timing.impl == WV_IMPL_FUSED) fused_dump_stamps(c->fused, st);
     float ms = 0.0f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
