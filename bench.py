@@ -17,6 +17,7 @@ energy traces are all-gathered after the last step inside it.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -101,14 +102,13 @@ def batched_envs(w, dim, ds, dev, impl, n_envs, pml_width, actions=6):
         envs.append(env)
         pols.append(w.RandomDesignPolicy(env.action_space(), np.random.default_rng(700 + e)))
 
-    def sweep():
-        for env, pol in zip(envs, pols):
-            env.step_begin(pol(env))
-        for env in envs:
-            env.step_end()
+    def sweep():  # at most 4 actions in flight at a time (w.step_all): the aggregate peaks there
+        w.step_all(envs, [pol(env) for env, pol in zip(envs, pols)])
 
     sweep()
     sweep()
+    gc.collect()
+    gc.freeze()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(actions):
@@ -121,7 +121,8 @@ def batched_envs(w, dim, ds, dev, impl, n_envs, pml_width, actions=6):
         env.ctx.close()
     return {"envs_per_gpu": n_envs, "value": round(val, 2), "unit": "Mcell-updates/s",
             "whole_job_frac": round(B_ALG * val * 1e6 / (HBM_PEAK_GBS * 1e9), 4),
-            "note": "independent envs overlapped on separate HIP streams (BASELINE config 3 shape); not the headline"}
+            "note": "independent envs overlapped on separate HIP streams, 4 in flight at a time (BASELINE config 3 shape); "
+                    "not the headline"}
 
 
 def main():
@@ -133,10 +134,9 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=40, help="integration steps of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--grid", type=int, default=N_GRID, help="grid points per axis (700 = the metric's configuration)")
     ap.add_argument("--pml-width", type=float, default=2.0)
-    ap.add_argument("--batch-envs", type=int, default=4,
-                    help="extra (untimed-for-`value`) measurement: this many independent envs stepped concurrently on the "
-                         "GPU, the shape of BASELINE config 3 (0 = skip).  4 is where the aggregate peaks on one MI355X; "
-                         "config 3's literal 8 per GPU gives about half of it (measured)")
+    ap.add_argument("--batch-envs", type=int, default=8,
+                    help="extra (untimed-for-`value`) measurement: this many independent envs on the GPU, BASELINE config "
+                         "3's 8-per-GPU shape, stepped four at a time on their HIP streams (0 = skip)")
     args = ap.parse_args()
 
     import torch  # first: the HIP runtime both torch and libwaves_amd use is then torch's
@@ -169,6 +169,11 @@ def main():
         env(policy(env))
     if world > 1:
         wd.gather_signals(env.signal)  # warm the communicator up outside the timed region
+    # A full collection of the interpreter's cyclic GC takes 30-50 ms once torch is imported (millions of objects) and
+    # would land in the middle of a 1.3 ms action every few hundred allocations: park everything allocated so far in the
+    # permanent generation, as long-running Python services do.
+    gc.collect()
+    gc.freeze()
 
     wd.barrier()
     torch.cuda.synchronize()

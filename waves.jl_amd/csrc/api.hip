@@ -601,7 +601,9 @@ struct HostProf {
     {
         if (!on) return;
         const auto n = std::chrono::steady_clock::now();
-        acc[k] += std::chrono::duration<double, std::micro>(n - t).count();
+        const double us = std::chrono::duration<double, std::micro>(n - t).count();
+        acc[k] += us;
+        if (us > 3000.0) fprintf(stderr, "[waves_amd hostprof] section %d of wv_integrate_begin took %.1f ms\n", k, us / 1000.0);
         t = n;
     }
     ~HostProf()

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "fused.h"
@@ -565,11 +566,14 @@ int fused_prepare(FusedPlan *p, float *frames, float *scratch0, float *scratch1,
     }
     const size_t ni = p->idx.size() ? p->idx.size() : 1;
     if (ni > p->idx_cap) {
+        // generous: the list grows and shrinks from call to call with the design, and a new device pointer is a new
+        // kernel argument, i.e. a re-instantiation of the cached hipGraph (~40 ms)
+        const size_t want = std::max(2 * ni, nt * 16);
         if (p->d_idx) (void)hipFree(p->d_idx);
         p->d_idx = nullptr;
         p->idx_cap = 0;
-        if (hipMalloc((void **)&p->d_idx, ni * sizeof(int)) != hipSuccess) return 1;
-        p->idx_cap = ni;
+        if (hipMalloc((void **)&p->d_idx, want * sizeof(int)) != hipSuccess) return 1;
+        p->idx_cap = want;
     }
     if (hipMemcpyAsync(p->d_tiles, p->hp.tiles.data(), nt * sizeof(TileDesc), hipMemcpyHostToDevice, s) != hipSuccess) return 1;
     if (!p->idx.empty() &&
@@ -795,6 +799,7 @@ int fused_run(FusedPlan *pl, const FusedCall &call, const FusedStep *steps, int 
     key_put(key, pl->nbands);
     for (int i = 0; i < nsteps; ++i) key_put(key, steps[i]);
     if (!pl->graph_exec || key != pl->graph_key) {
+        if (getenv("WAVES_AMD_HOSTPROF")) fprintf(stderr, "[waves_amd] (re)building the step graph of plan %p\n", (void *)pl);
         if (pl->graph_exec) (void)hipGraphExecDestroy(pl->graph_exec);
         if (pl->graph) (void)hipGraphDestroy(pl->graph);
         pl->graph_exec = nullptr;
