@@ -97,3 +97,31 @@ def test_pml_decay_2048():
     sig, _, _ = ctx.integrate(wo.build_tspan(0.0, 1e-5, 2000))
     ctx.close()
     assert sig[-1, 0] < 0.02 * sig[0, 0]
+
+
+def test_step_all_overlapped_envs_equal_sequential_stepping():
+    """Several environments on one GPU stepped through w.step_all (groups of actions in flight on the envs' HIP streams,
+    single-step kernels) give exactly what stepping them one after the other gives."""
+    def make(seed):
+        dim = w.TwoDim(15.0, 220)
+        src = w.RandomPosGaussianSource(w.build_grid(dim), [[-10.0, -10.0]], [[-10.0, 10.0]], [0.3], [1.0], 1000.0,
+                                        rng=np.random.default_rng(seed))
+        env = w.WaveEnv(dim, design_space=w.build_triple_ring_design_space(), source=src, integration_steps=25, actions=4,
+                        rng=np.random.default_rng(seed + 1), return_fields=False)
+        env.reset()
+        return env, w.RandomDesignPolicy(env.action_space(), np.random.default_rng(seed + 2))
+
+    seq = []
+    for k in range(3):
+        env, pol = make(10 * k)
+        for _ in range(2):
+            env(pol(env))
+        seq.append((np.array(env.signal), env.ctx.get_frames()))
+        env.ctx.close()
+    envs, pols = zip(*[make(10 * k) for k in range(3)])
+    for _ in range(2):
+        w.step_all(envs, [p(e) for e, p in zip(envs, pols)], max_in_flight=2)
+    for k, env in enumerate(envs):
+        assert env.ctx.timing()["resident"] is False          # three live contexts share the device
+        assert np.array_equal(env.signal, seq[k][0]) and np.array_equal(env.ctx.get_frames(), seq[k][1])
+        env.ctx.close()
