@@ -271,6 +271,19 @@ static int run_case(const Case &cs)
     }
     std::vector<int> idx;
     plan_build_cyl(pl, x.data(), x.data(), table.data(), M, 3 * nsteps, idx);
+    {   // the culling from the rows of the earliest / latest stage time only (what api.hip passes) must give the same lists
+        HostPlan pl2 = pl;
+        std::vector<int> idx2;
+        plan_build_cyl(pl2, x.data(), x.data(), table.data(), M, 3 * nsteps, idx2, true, 0, 0, 3 * nsteps - 1);
+        bool same = idx2 == idx && pl2.tiles.size() == pl.tiles.size();
+        for (size_t k = 0; same && k < pl.tiles.size(); ++k)
+            same = pl.tiles[k].slot == pl2.tiles[k].slot && pl.tiles[k].cyl_begin == pl2.tiles[k].cyl_begin &&
+                   pl.tiles[k].cyl_count == pl2.tiles[k].cyl_count;
+        if (!same) {
+            printf("%-28s culling from the two extreme rows differs from the full scan\n", cs.name);
+            return 1;
+        }
+    }
 
     // per-tile source flags exactly as k_src_flags computes them
     std::vector<unsigned char> flags(pl.tiles.size(), 0);

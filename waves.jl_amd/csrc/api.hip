@@ -639,14 +639,21 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     // per-stage coefficient tables: stage times t, t + 0.5f0*dt, t + dt (src/dynamics.jl:10-13)
     c->h_sfac.assign(3 * (size_t)nsteps, 0.0f);
     c->h_cyl.resize(3 * (size_t)nsteps * (M > 0 ? M : 1));
+    int row_lo = 0, row_hi = 0;  // rows of the earliest / latest stage time (bounding boxes of the cylinder culling)
+    float t_lo = INFINITY, t_hi = -INFINITY;
+    bool t_ok = true;
     for (int s = 0; s < nsteps; ++s) {
         const float t = tspan[s];
         const float tq[3] = {t, t + hdt, t + dt};
         for (int q = 0; q < 3; ++q) {
             if (c->has_source) c->h_sfac[3 * s + q] = source_factor(tq[q], c->freq);
             if (M > 0) design_at(c, tq[q], c->h_cyl.data() + (size_t)(3 * s + q) * M);
+            t_ok = t_ok && isfinite(tq[q]);
+            if (tq[q] < t_lo) { t_lo = tq[q]; row_lo = 3 * s + q; }
+            if (tq[q] > t_hi) { t_hi = tq[q]; row_hi = 3 * s + q; }
         }
     }
+    if (!t_ok) row_lo = row_hi = -1;  // (a NaN time: let the culling look at every row)
     g_hostprof.lap(0);
     int rc = ensure(c, &c->d_cyl, &c->cyl_cap, c->h_cyl.size());
     if (rc) return rc;
@@ -661,7 +668,7 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
         fused_allow_resident(c->fused, g_live_ctx[c->cfg.device & 63] <= 1);
         rc = fused_prepare(c->fused, c->d_frames, c->d_scratch[0], c->d_scratch[1], capture != 0,
                            c->has_source ? c->d_G : nullptr, c->d_cyl, M > 0 ? c->h_cyl.data() : nullptr, M, 3 * nsteps,
-                           c->stream);
+                           c->stream, row_lo, row_hi);
         if (rc) return fail(c, rc == 2 ? WV_ERR_INVALID : WV_ERR_HIP, "fused_prepare failed");
         if (fused_generation(c->fused) != c->elast_generation) c->elast_valid = false;
         c->elast_generation = fused_generation(c->fused);

@@ -40,8 +40,9 @@ void fused_dump_stamps(FusedPlan *p, hipStream_t s);  // diagnostic, no-op unles
 // Called once per wv_integrate before the first step: d_table = device cylinder table (rows x M), h_table its host copy.
 // frames = env.wave (3 states, the last one is the initial condition), scratch0/1 the two ping-pong states.
 // G = device source shape or nullptr (NoSource).
+// row_lo / row_hi: rows of h_table with the earliest / latest stage time (see plan_build_cyl), or -1.
 int fused_prepare(FusedPlan *p, float *frames, float *scratch0, float *scratch1, bool capture, const float *G,
-                  const Cyl *d_table, const Cyl *h_table, int M, int rows, hipStream_t s);
+                  const Cyl *d_table, const Cyl *h_table, int M, int rows, hipStream_t s, int row_lo = -1, int row_hi = -1);
 void fused_source_changed(FusedPlan *p);  // the source shape was replaced
 // one step, eagerly, as a single launch over all tiles (profiling mode brackets these with events)
 void fused_launch(FusedPlan *p, const FusedCall &call, int step, const FusedStep &st, hipStream_t s);

@@ -283,8 +283,11 @@ inline void plan_pair_order(HostPlan &pl, int pair_cus)
 // Per-tile list of the cylinders whose disc can reach the tile's region at ANY of the `rows` stage times of this
 // integrate call.  Conservative bounding boxes with a safety margin far above fp32 round-off: a culled cylinder must
 // have mask == false at every cell of the region, in which case dropping it is exact (it would add +0).
+// row_lo / row_hi (optional): the rows of the earliest and of the latest stage time.  The table is a linear interpolation
+// in time rounded monotonically (v_i + (k * tau), tau = clamp(t) - t_i), so every component takes its extremes over the
+// call at those two rows and the bounding boxes need no scan of all `rows`.
 inline void plan_build_cyl(HostPlan &pl, const float *x, const float *y, const Cyl *table, int M, int rows,
-                           std::vector<int> &idx, bool resort = true, int pair_cus = 0)
+                           std::vector<int> &idx, bool resort = true, int pair_cus = 0, int row_lo = -1, int row_hi = -1)
 {
     idx.clear();
     pl.tiles = pl.base;
@@ -298,7 +301,9 @@ inline void plan_build_cyl(HostPlan &pl, const float *x, const float *y, const C
     for (int m = 0; m < M; ++m) {
         double pxmin = INFINITY, pxmax = -INFINITY, pymin = INFINITY, pymax = -INFINITY, r2 = 0.0;
         bool ok = true;
-        for (int r = 0; r < rows; ++r) {
+        const bool ends = row_lo >= 0 && row_hi >= 0 && row_lo < rows && row_hi < rows;
+        for (int q = 0; q < (ends ? 2 : rows); ++q) {
+            const int r = ends ? (q == 0 ? row_lo : row_hi) : q;
             const Cyl &c = table[(size_t)r * M + m];
             if (!isfinite(c.px) || !isfinite(c.py) || !isfinite(c.r2)) ok = false;
             pxmin = std::min(pxmin, (double)c.px);

@@ -520,7 +520,7 @@ void fused_source_changed(FusedPlan *p) { p->src_dirty = true; }
 static int resident_capacity(FusedPlan *pl);
 
 int fused_prepare(FusedPlan *p, float *frames, float *scratch0, float *scratch1, bool capture, const float *G,
-                  const Cyl *d_table, const Cyl *h_table, int M, int rows, hipStream_t s)
+                  const Cyl *d_table, const Cyl *h_table, int M, int rows, hipStream_t s, int row_lo, int row_hi)
 {
     const Grid &g = p->g;
     const size_t N = g.P * kFields;
@@ -555,7 +555,8 @@ int fused_prepare(FusedPlan *p, float *frames, float *scratch0, float *scratch1,
     // (tiles that fit the device at once will run resident: order them for that kernel)
     static const bool pairing = !(getenv("WAVES_AMD_FUSED_PAIRING") && atoi(getenv("WAVES_AMD_FUSED_PAIRING")) == 0);
     const bool fits = (int)p->hp.tiles.size() <= resident_capacity(p);
-    plan_build_cyl(p->hp, p->x.data(), p->y.data(), h_table, M, rows, p->idx, resort, (fits && pairing) ? p->cu_count : 0);
+    plan_build_cyl(p->hp, p->x.data(), p->y.data(), h_table, M, rows, p->idx, resort, (fits && pairing) ? p->cu_count : 0,
+                   row_lo, row_hi);
     const size_t nt = p->hp.tiles.size();
     if (nt > p->tiles_cap) {
         if (p->d_tiles) (void)hipFree(p->d_tiles);
