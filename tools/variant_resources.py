@@ -11,7 +11,9 @@ OUT = os.path.join(ROOT, "gpurun_out", "variants")
 VARIANTS = [("AUX_NONE", "0", "RF"), ("AUX_NONE", "F_SRC", "RF"), ("AUX_NONE", "F_CYL | F_SRC", "RF"),
             ("AUX_PX", "F_EL | F_SRC", "RB"), ("AUX_PX", "F_ER | F_SRC", "RB"), ("AUX_PX", "F_ALL", "RB"),
             ("AUX_PY", "0", "RB"), ("AUX_PY", "F_ET | F_SRC", "RB"), ("AUX_PY", "F_EB | F_SRC", "RB"), ("AUX_PY", "F_ALL", "RB"),
-            ("AUX_ALL", "F_EDGE | F_SRC", "RP"), ("AUX_ALL", "F_ALL", "RP")]
+            ("AUX_ALL", "F_EDGE | F_SRC", "RP"), ("AUX_ALL", "F_ALL", "RP"),
+            ("AUX_PX", "F_EL", "RB"), ("AUX_PX", "F_ER", "RB"), ("AUX_PY", "F_ET", "RB"), ("AUX_PY", "F_EB", "RB"),
+            ("AUX_ALL", "F_EDGE", "RP")]
 
 
 def main():

@@ -97,16 +97,22 @@ __global__ __launch_bounds__(NW * 64, 4) void k_step_fused(FusedParams p_)  // 4
         else if (fl == F_SRC) RUN(AUX_NONE, F_SRC, RF);
         else RUN(AUX_NONE, F_CYL | F_SRC, RF);
     } else if (t.aux == AUX_PX) {
-        if (!cyl && (fe & ~F_EL) == 0) RUN(AUX_PX, F_EL | F_SRC, RB);  // left strip, or a PML strip off the boundary
+        const bool src = (fl & F_SRC) != 0;  // (the source rarely reaches the PML: its own variants without it)
+        if (!cyl && !src && (fe & ~F_EL) == 0) RUN(AUX_PX, F_EL, RB);  // left strip, or a PML strip off the boundary
+        else if (!cyl && !src && (fe & ~F_ER) == 0) RUN(AUX_PX, F_ER, RB);
+        else if (!cyl && (fe & ~F_EL) == 0) RUN(AUX_PX, F_EL | F_SRC, RB);
         else if (!cyl && (fe & ~F_ER) == 0) RUN(AUX_PX, F_ER | F_SRC, RB);
         else RUN(AUX_PX, F_ALL, RB);
     } else if (t.aux == AUX_PY) {
         if (fl == 0) RUN(AUX_PY, 0, RB);
+        else if (!cyl && (fl & F_SRC) == 0 && (fe & ~F_ET) == 0) RUN(AUX_PY, F_ET, RB);
+        else if (!cyl && (fl & F_SRC) == 0 && (fe & ~F_EB) == 0) RUN(AUX_PY, F_EB, RB);
         else if (!cyl && (fe & ~F_ET) == 0) RUN(AUX_PY, F_ET | F_SRC, RB);
         else if (!cyl && (fe & ~F_EB) == 0) RUN(AUX_PY, F_EB | F_SRC, RB);
         else RUN(AUX_PY, F_ALL, RB);
     } else {
-        if (!cyl) RUN(AUX_ALL, F_EDGE | F_SRC, RP);
+        if (!cyl && (fl & F_SRC) == 0) RUN(AUX_ALL, F_EDGE, RP);
+        else if (!cyl) RUN(AUX_ALL, F_EDGE | F_SRC, RP);
         else RUN(AUX_ALL, F_ALL, RP);
     }
 #undef RUN
@@ -305,16 +311,22 @@ __global__ __launch_bounds__(NW * 64, 4) void k_steps_resident(FusedParams p_)
         else if (fl == F_SRC) RUN(AUX_NONE, F_SRC, RF);
         else RUN(AUX_NONE, F_CYL | F_SRC, RF);
     } else if (t.aux == AUX_PX) {
-        if (!cyl && (fe & ~F_EL) == 0) RUN(AUX_PX, F_EL | F_SRC, RB);
+        const bool src = (fl & F_SRC) != 0;
+        if (!cyl && !src && (fe & ~F_EL) == 0) RUN(AUX_PX, F_EL, RB);
+        else if (!cyl && !src && (fe & ~F_ER) == 0) RUN(AUX_PX, F_ER, RB);
+        else if (!cyl && (fe & ~F_EL) == 0) RUN(AUX_PX, F_EL | F_SRC, RB);
         else if (!cyl && (fe & ~F_ER) == 0) RUN(AUX_PX, F_ER | F_SRC, RB);
         else RUN(AUX_PX, F_ALL, RB);
     } else if (t.aux == AUX_PY) {
         if (fl == 0) RUN(AUX_PY, 0, RB);
+        else if (!cyl && (fl & F_SRC) == 0 && (fe & ~F_ET) == 0) RUN(AUX_PY, F_ET, RB);
+        else if (!cyl && (fl & F_SRC) == 0 && (fe & ~F_EB) == 0) RUN(AUX_PY, F_EB, RB);
         else if (!cyl && (fe & ~F_ET) == 0) RUN(AUX_PY, F_ET | F_SRC, RB);
         else if (!cyl && (fe & ~F_EB) == 0) RUN(AUX_PY, F_EB | F_SRC, RB);
         else RUN(AUX_PY, F_ALL, RB);
     } else {
-        if (!cyl) RUN(AUX_ALL, F_EDGE | F_SRC, RP);
+        if (!cyl && (fl & F_SRC) == 0) RUN(AUX_ALL, F_EDGE, RP);
+        else if (!cyl) RUN(AUX_ALL, F_EDGE | F_SRC, RP);
         else RUN(AUX_ALL, F_ALL, RP);
     }
 #undef RUN
