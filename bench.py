@@ -233,9 +233,10 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and ngrid == N_GRID:
+        if os.path.exists(tpath) and (ngrid == N_GRID or (ngrid == 2048 and args.pml_width == 2.0)):
             try:
-                traffic = json.load(open(tpath)).get("resident" if resident else impl)
+                key = "resident" if resident else impl
+                traffic = json.load(open(tpath)).get(key if ngrid == N_GRID else f"{key}_{ngrid}")
             except Exception:
                 traffic = None
         kname = "k_steps_resident" if resident else ("k_step_fused" if impl == "fused" else "k_stage")
