@@ -152,6 +152,12 @@ int wv_rhs(wv_ctx *ctx, const float *x /* 12*nx*ny */, float t, float *k /* 12*n
  * Synchronous: outputs are ready on return. */
 int wv_integrate(wv_ctx *ctx, const float *tspan, int nsteps, int capture_frames, float *signal, float *u_tot,
                  float *u_inc);
+/* Trajectories for rendering (render! / build_interpolator, src/plot.jl:24-45, scripts/mpc.jl:65-108) do not need every
+ * saved time: with stride k the u_tot / u_inc outputs of wv_integrate hold the saved times 0, k, 2k, ... <= nsteps, i.e.
+ * nsteps / k + 1 planes each (k = 1, the default, is the reference's sol[:, :, 1|7, :] of src/env.jl:113,120: all
+ * nsteps + 1).  The 396 MB device-to-host copy of a 700^2 action shrinks by k; signal and frames are unaffected. */
+int wv_set_trajectory_stride(wv_ctx *ctx, int stride);
+
 /* The same split in two so that several ctxs on one device overlap: _begin enqueues all device work and returns,
  * _end waits and copies the outputs.  Exactly one _end per _begin. */
 int wv_integrate_begin(wv_ctx *ctx, const float *tspan, int nsteps, int capture_frames, int want_signal,

@@ -539,3 +539,27 @@ def test_episode_with_observations_windowing_and_file_round_trip(tmp_path):
     assert all(np.array_equal(b.wave, e.wave) for b, e in zip(back.s, ep.s))
     assert all(np.array_equal(b, e) for b, e in zip(back.y, ep.y))
     env.ctx.close()
+
+
+def test_strided_trajectories_are_a_subsampling_of_the_full_ones(monkeypatch):
+    """SURVEY 8f rank 3 (the byte-saving half): with wv_set_trajectory_stride(k) the u_tot / u_inc outputs hold the saved
+    times 0, k, 2k, ...; everything else is unchanged.  Both step kernels."""
+    import gc
+    for resident in ("1", "0"):
+        gc.collect()
+        monkeypatch.setenv("WAVES_AMD_FUSED_RESIDENT", resident)
+        outs = {}
+        for k in (1, 4, 7):
+            dim, ctx = make_ctx(150, "fused")
+            ctx.set_gaussian_source([[1.0, -2.0]], [0.4], [1.0], 1000.0)
+            ctx.set_trajectory_stride(k)
+            sig, ut, ui = ctx.integrate(wo.build_tspan(0.0, 1e-5, 30), capture_frames=True, want_fields=True)
+            outs[k] = (sig, ut, ui, ctx.get_frames())
+            ctx.close()
+        full = outs[1]
+        assert full[1].shape == (150, 150, 31)
+        for k in (4, 7):
+            sig, ut, ui, fr = outs[k]
+            assert ut.shape == (150, 150, 30 // k + 1)
+            assert np.array_equal(ut, full[1][:, :, ::k]) and np.array_equal(ui, full[2][:, :, ::k])
+            assert np.array_equal(sig, full[0]) and np.array_equal(fr, full[3])

@@ -96,6 +96,7 @@ def lib():
     _sig(L, "wv_integrate", [ctx, _fp, C.c_int, C.c_int, _fp, _fp, _fp])
     _sig(L, "wv_integrate_begin", [ctx, _fp, C.c_int, C.c_int, C.c_int, C.c_int])
     _sig(L, "wv_integrate_end", [ctx, _fp, _fp, _fp])
+    _sig(L, "wv_set_trajectory_stride", [ctx, C.c_int])
     _sig(L, "wv_set_profiling", [ctx, C.c_int])
     _sig(L, "wv_get_timing", [ctx, C.POINTER(wv_timing)])
     _sig(L, "wv_set_stream", [ctx, _vp])
@@ -272,6 +273,11 @@ class Context:
         self.integrate_begin(tspan, capture_frames=capture_frames, want_signal=want_signal, want_fields=want_fields)
         return self.integrate_end()
 
+    def set_trajectory_stride(self, stride: int):
+        """u_tot / u_inc of later integrate calls hold every `stride`-th saved time (0, stride, ...)."""
+        self._ck(self._L.wv_set_trajectory_stride(self._h, int(stride)))
+        self._traj_stride = int(stride)
+
     def integrate_begin(self, tspan, *, capture_frames=False, want_signal=True, want_fields=False):
         ts = np.ascontiguousarray(tspan, np.float32).reshape(-1)
         n = len(ts) - 1
@@ -282,8 +288,9 @@ class Context:
     def integrate_end(self):
         n, ws, wf = self._pend
         sig = np.empty((n + 1, 3), np.float32) if ws else None
-        ut = np.empty((self.nx, self.ny, n + 1), np.float32, order="F") if wf else None
-        ui = np.empty((self.nx, self.ny, n + 1), np.float32, order="F") if wf else None
+        planes = n // getattr(self, "_traj_stride", 1) + 1
+        ut = np.empty((self.nx, self.ny, planes), np.float32, order="F") if wf else None
+        ui = np.empty((self.nx, self.ny, planes), np.float32, order="F") if wf else None
         self._ck(self._L.wv_integrate_end(self._h, fptr(sig), fptr(ut), fptr(ui)))
         return sig, ut, ui
 

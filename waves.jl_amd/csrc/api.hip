@@ -52,6 +52,8 @@ struct wv_ctx {
     size_t h_signal_cap = 0;
     size_t signal_cap = 0;
     float *d_traj = nullptr;
+    int traj_stride = 1;       // wv_set_trajectory_stride: every traj_stride-th saved time goes to u_tot / u_inc
+    int pend_planes = 0;       // planes per trajectory of the pending call
     size_t traj_cap = 0;
     float *d_small = nullptr;  // gaussian parameters
     size_t small_cap = 0;
@@ -684,8 +686,10 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
         rc = ensure(c, &c->d_signal, &c->signal_cap, (size_t)(nsteps + 1) * 3);
         if (rc) return rc;
     }
+    const int tstride = c->traj_stride;
+    const int nplanes = nsteps / tstride + 1;  // saved times 0, stride, 2*stride, ... <= nsteps
     if (want_fields) {
-        rc = ensure(c, &c->d_traj, &c->traj_cap, (size_t)2 * (nsteps + 1) * c->P);
+        rc = ensure(c, &c->d_traj, &c->traj_cap, (size_t)2 * nplanes * c->P);
         if (rc) return rc;
     }
     {  // one pair of events always (it brackets the fused launch(es) of the call), one pair per step when profiling
@@ -702,7 +706,7 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     HIPCHK(c, hipEventRecord(c->ev0, st));
 
     float *tt = want_fields ? c->d_traj : nullptr;                               // u_tot planes
-    float *ti_ = want_fields ? c->d_traj + (size_t)(nsteps + 1) * c->P : nullptr;  // u_inc planes
+    float *ti_ = want_fields ? c->d_traj + (size_t)nplanes * c->P : nullptr;        // u_inc planes
 
     float *cur = frame(c, 2);
     if (want_signal) {
@@ -732,8 +736,9 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
         const Cyl *cyl_s = c->d_cyl + (size_t)(3 * (s - 1)) * (M > 0 ? M : 0);
         const float *sf = c->h_sfac.data() + 3 * (size_t)(s - 1);
         float *ep = want_signal ? c->d_epart + (size_t)s * nblocks * 3 : nullptr;
-        float *tts = tt ? tt + (size_t)s * c->P : nullptr;
-        float *tis = ti_ ? ti_ + (size_t)s * c->P : nullptr;
+        const bool keep_t = s % tstride == 0;
+        float *tts = (tt && keep_t) ? tt + (size_t)(s / tstride) * c->P : nullptr;
+        float *tis = (ti_ && keep_t) ? ti_ + (size_t)(s / tstride) * c->P : nullptr;
         const float *G = c->has_source ? c->d_G : nullptr;
         if (c->profiling && impl == WV_IMPL_STAGED) HIPCHK(c, hipEventRecord(c->kev[2 * (s - 1)], st));
         if (impl == WV_IMPL_STAGED) {
@@ -827,6 +832,7 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     c->pend_nsteps = nsteps;
     c->pend_signal = want_signal != 0;
     c->pend_fields = want_fields != 0;
+    c->pend_planes = nplanes;
     c->timing = wv_timing{};
     c->timing.steps = nsteps;
     c->timing.impl = impl;
@@ -844,10 +850,9 @@ int wv_integrate_end(wv_ctx *c, float *signal, float *u_tot, float *u_inc)
     if (signal && !c->pend_signal) return fail(c, WV_ERR_STATE, "wv_integrate_end: signal was not requested in _begin");
     if ((u_tot || u_inc) && !c->pend_fields) return fail(c, WV_ERR_STATE, "wv_integrate_end: fields were not requested in _begin");
     hipStream_t st = c->stream;
-    if (u_tot) HIPCHK(c, hipMemcpyAsync(u_tot, c->d_traj, (size_t)(n + 1) * c->P * sizeof(float), hipMemcpyDeviceToHost, st));
-    if (u_inc)
-        HIPCHK(c, hipMemcpyAsync(u_inc, c->d_traj + (size_t)(n + 1) * c->P, (size_t)(n + 1) * c->P * sizeof(float),
-                                 hipMemcpyDeviceToHost, st));
+    const size_t tp = (size_t)c->pend_planes * c->P;
+    if (u_tot) HIPCHK(c, hipMemcpyAsync(u_tot, c->d_traj, tp * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (u_inc) HIPCHK(c, hipMemcpyAsync(u_inc, c->d_traj + tp, tp * sizeof(float), hipMemcpyDeviceToHost, st));
     if (!u_tot && !u_inc) {
         // everything the caller gets is already on its way (or here): poll the call's last event for a while before
         // falling back to a blocking wait
@@ -905,6 +910,15 @@ int wv_integrate(wv_ctx *c, const float *tspan, int nsteps, int capture, float *
     int rc = wv_integrate_begin(c, tspan, nsteps, capture, signal != nullptr, (u_tot || u_inc) ? 1 : 0);
     if (rc) return rc;
     return wv_integrate_end(c, signal, u_tot, u_inc);
+}
+
+int wv_set_trajectory_stride(wv_ctx *c, int stride)
+{
+    CHECK_CTX(c);
+    if (stride < 1) return fail(c, WV_ERR_INVALID, "wv_set_trajectory_stride: stride must be >= 1");
+    if (c->pending) return fail(c, WV_ERR_STATE, "wv_set_trajectory_stride: an integrate is pending");
+    c->traj_stride = stride;
+    return WV_OK;
 }
 
 int wv_set_profiling(wv_ctx *c, int on)

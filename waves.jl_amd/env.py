@@ -25,7 +25,7 @@ class WaveEnv:
 
     def __init__(self, dim: TwoDim, *, design_space: DesignSpace, action_speed=250.0, source=None, c0=WATER,
                  pml_width=2.0, pml_scale=20000.0, resolution=(128, 128), dt=1e-5, integration_steps=100, actions=10,
-                 device=0, impl="auto", rng=None, return_fields=True):
+                 device=0, impl="auto", rng=None, return_fields=True, trajectory_stride=1):
         if not all(s > r for s, r in zip(dim.size(), resolution)):  # src/env.jl:52
             raise AssertionError("Resolution must be less than finite element grid.")
         self.rng = rng if rng is not None else np.random.default_rng()
@@ -45,6 +45,9 @@ class WaveEnv:
         self.integration_steps = int(integration_steps)
         self.actions = int(actions)
         self.return_fields = return_fields
+        self.trajectory_stride = int(trajectory_stride)   # u_tot / u_inc of env(action) hold every k-th saved time
+        if self.trajectory_stride != 1:
+            self.ctx.set_trajectory_stride(self.trajectory_stride)
 
     # --- src/env.jl:69-79
     def time(self):
