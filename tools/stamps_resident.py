@@ -42,3 +42,11 @@ for nm, m in (("NONE cyl=0", (aux == 0) & (cyl == 0)), ("NONE cyl>0", (aux == 0)
     if m.any():
         print(f"  {nm:11s} n={m.sum():3d} {np.mean(X[m,7]-X[m,0]):6.0f} | {np.mean(X[m,8]-X[m,7]):6.0f} | {np.mean(X[m,9]-X[m,8]):6.0f} | "
               f"{np.mean(X[m,11]-X[m,9]):6.0f} | {np.mean(X[m,1]-X[m,11]):6.0f}")
+
+tot = T[:, 5] - T[:, 0]
+print("step total percentiles ns:", np.percentile(tot, [0, 10, 50, 90, 99, 100]).round())
+print("slowest tiles by step total:")
+for i in np.argsort(-tot)[:14]:
+    print(f"  pos {a[i,0]:3d} slot {a[i,1]:3d} x0={a[i,2]:3d} y0={a[i,3]:3d} ox={a[i,4]} oy={a[i,5]} {names[aux[i]]:4s} edge={a[i,6]>>4} cyl={a[i,7]:3d} "
+          f"init+pub={X[i,7]-X[i,0]:.0f} speed={X[i,8]-X[i,7]:.0f} st1={X[i,9]-X[i,8]:.0f} st23={X[i,11]-X[i,9]:.0f} st4={X[i,1]-X[i,11]:.0f} "
+          f"store={d[i,1]:.0f} ack={d[i,2]:.0f} wait={d[i,3]:.0f} total={tot[i]:.0f}")

@@ -496,7 +496,11 @@ WV_HD bool fused_xch_load(const FusedParams &p, unsigned tag, const TileDesc &t,
         const int cgy = gy < 0 ? 0 : (gy >= p.ny ? p.ny - 1 : gy);
         const unsigned off = ((unsigned)cgy * (unsigned)p.nx + (unsigned)cgx) * 16u;
         const bool own = ownx && ly >= FT_H && ly < FT_H + t.oy;
+#ifdef WV_XCH_NOLOAD  // (timing experiment only: no halo is read at all)
+        const bool need = false && in;
+#else
         const bool need = in && !own;
+#endif
         // With reduced field sets the owner of a halo cell carries -- and sends -- an auxiliary field only where that
         // field can be non-zero (Psi_x: sigma_x != 0 in the column, Psi_y: sigma_y != 0 in the row, Omega: both); anywhere
         // else its value is the exact zero the field-set invariant guarantees, and there is no word to wait for.
