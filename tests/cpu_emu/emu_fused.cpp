@@ -312,7 +312,7 @@ static int run_case(const Case &cs)
     p.sfac_tab = sfac.data(); p.cyl_tab = table.data(); p.M = M; p.tile_offset = 0;
     p.dt = dt; p.hdt = hdt;
     p.tiles = pl.tiles.data(); p.cyl_idx = idx.data();
-    std::vector<unsigned long long> xch(cs.resident ? (size_t)2 * 12 * P : 1, 0ull);
+    std::vector<unsigned long long> xch(cs.resident ? (size_t)2 * XCH_PLANES * 2 * P : 2, 0ull);
     p.xch = xch.data();
     p.xch_bytes = (unsigned)(xch.size() * sizeof(unsigned long long));
     p.tag_base = 4094;  // arbitrary; even + odd tags both occur

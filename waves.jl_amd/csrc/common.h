@@ -39,12 +39,26 @@ __device__ __forceinline__ float speed_at(float x, float y, const Cyl *__restric
     return C0 + cd;
 }
 
-// wave64 sum by shuffles (cdna_hip_programming.md Appendix B "Reduction")
+// wave64 sum, returned to every lane.  Six DPP adds (butterfly inside a row of 16 lanes, then row broadcasts) instead of
+// six dependent LDS-crossbar shuffles: the sum of a wave is on the critical path between two steps of k_steps_resident.
+// The order of the additions is fixed, so results are deterministic (cdna_hip_programming.md Appendix B "Reduction").
 __device__ __forceinline__ float wave_sum(float v)
 {
+#ifdef WV_SHFL_SUM
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
+    return __shfl(v, 0, 64);
+#endif
+#define WV_DPP_ADD(ctrl, rmask) \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+    WV_DPP_ADD(0xb1, 0xf);   // quad_perm [1,0,3,2]: neighbour
+    WV_DPP_ADD(0x4e, 0xf);   // quad_perm [2,3,0,1]: other pair -> every lane holds its quad's sum
+    WV_DPP_ADD(0x141, 0xf);  // row_half_mirror: the other quad of the 8 lanes
+    WV_DPP_ADD(0x140, 0xf);  // row_mirror: the other half of the 16 lanes -> every lane holds its row's sum
+    WV_DPP_ADD(0x142, 0xa);  // row_bcast15 into rows 1 and 3: they hold the sum of 32 lanes
+    WV_DPP_ADD(0x143, 0xc);  // row_bcast31 into rows 2 and 3: lane 63 holds the sum of the wave
+#undef WV_DPP_ADD
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 }  // namespace wv

@@ -90,7 +90,7 @@ struct FusedParams {
     // k_steps_resident: all steps of the call in one launch, every tile resident for the whole call
     const StepIO *steps;       // [nsteps]; steps[s].u == steps[s-1].out
     int nsteps;
-    unsigned long long *xch;   // halo exchange: [2 parities][6 fields][P cells][2 sets] words of (tag << 32 | value bits)
+    unsigned long long *xch;   // halo exchange: [2 parities][4 planes][P cells] 16-byte granules {3 values, tag}, see fused_xch_*
     unsigned xch_bytes;        // its size
     unsigned tag_base;         // the border cells of step s carry the tag tag_base + s + 1
     int *abort;                // set when a wait gave up: every tile then leaves the kernel
@@ -358,15 +358,35 @@ WV_HD void fused_load_state(const FusedParams &p, const float *u, const TileDesc
 
 // ---- halo exchange of k_steps_resident ----------------------------------------------------------------------------
 // A resident tile keeps its own output cells in registers from step to step; what it needs from outside is the halo
-// ring, i.e. the outermost FT_H cells of the neighbouring tiles' outputs.  Those travel through p.xch as 8-byte words
-// carrying the value AND the step tag, written and read with single agent-scope atomic accesses (write-through / served
-// from memory, coherent across the XCDs without cache maintenance): a reader that finds the expected tag has the value
-// -- no flag, no acknowledgement to wait for, no ordering between different words needed.  One buffer per tag parity:
-// a tile can only write the border of step s+2 after it has read its neighbours' borders of step s+1, which they
-// wrote after reading this tile's border of step s -- so nobody still needs the word that is being overwritten.
-// (On the device the value crosses into / out of the 64-bit word through an explicit register copy: otherwise the
-// register coalescer makes the long-lived state value a sub-register of the word's aligned register pair -- 24 state
-// values then occupy 24 PAIRS for the whole step, and the kernel spills.)
+// ring, i.e. the outermost FT_H cells of the neighbouring tiles' outputs.  Those travel through p.xch as 16-byte
+// GRANULES {three field values, step tag}, each written by ONE agent-scope (sc1, write-through) 16-byte store and read by
+// ONE agent-scope 16-byte load: a reader that finds the expected tag has the three values -- no flag, no acknowledgement
+// to wait for, no ordering between different granules needed.  One buffer per tag parity: a tile can only write the
+// border of step s+2 after it has read its neighbours' borders of step s+1, which they wrote after reading this tile's
+// border of step s -- so nobody still needs the granule that is being overwritten.
+//
+// What this relies on: a 16-byte-aligned 16-byte access of one lane is never observed torn (tag of one store, values of
+// another).  The ISA does not promise it (only naturally aligned accesses up to 8 bytes are atomics the compiler itself
+// emits); it holds on gfx950 because such an access lies within one 32-byte sector of one 64-byte request on every hop
+// (vector L1 -> L2 -> fabric -> memory side), and requests are not split below a sector: tools/micro/tear16.hip looks for
+// a torn granule under load from all XCDs (1.5e11 checked loads, none torn: profiles/r02/tear16_b128.txt), and
+// tests/test_gpu_parity.py runs it (wv_selftest_granules) on the device the tests run on.
+//
+// Why granules and not one tagged word per value: three values per tag instead of one -- 25 % fewer bytes and a third
+// fewer vector-memory instructions in the exchange burst that every tile issues at the same moment of a step.
+// (Measured and NOT done: letting the idle neighbour lanes of an x-border row carry the incident granule, with the values
+// crossing the 4 lanes by ds_bpermute -- one instruction per such row instead of two -- cost 4 %: the two dependent
+// LDS-crossbar round trips sit on the critical path of the exchange, the saved instructions do not.)
+//
+// Layout: [tag parity (2)][granule plane (4)][cell (P)] 16-byte granules.  Planes 0 / 1: {U, Vx, Vy} of the total /
+// incident set.  Planes 2 / 3 depend on the CELL's damping class (both sides derive it from sigma_x, sigma_y at the
+// cell, so writer and reader agree whatever field sets their tiles carry):
+//   class 0  sigma_x == 0, sigma_y == 0 : nothing (the auxiliary fields are the exact zeros the field-set invariant guarantees)
+//   class 1  sigma_x != 0 only          : plane 2 = {Psi_x total, Psi_x incident, -}
+//   class 2  sigma_y != 0 only          : plane 2 = {Psi_y total, Psi_y incident, -}
+//   class 3  both (or p.reduced == 0)   : plane 2 = {Psi_x, Psi_y, Omega} total, plane 3 = the same of the incident set
+// (On the device a value crosses into / out of the 128-bit word through an explicit register copy: otherwise the register
+// coalescer makes the long-lived state value a sub-register of the word's aligned register tuple, and the kernel spills.)
 WV_HD unsigned xch_copy(unsigned v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -377,8 +397,8 @@ WV_HD unsigned xch_copy(unsigned v)
     return v;
 #endif
 }
-// keeps the compiler from hoisting the per-word address arithmetic out of the poll loop (24 address pairs kept live
-// across it) -- formed next to the load it folds into the instruction's scalar-base + 32-bit-offset addressing
+// keeps the compiler from hoisting the per-granule address arithmetic out of the poll loop -- formed next to the load it
+// folds into the instruction's scalar-base + 32-bit-offset addressing
 WV_HD unsigned xch_opaque(unsigned off)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -386,13 +406,10 @@ WV_HD unsigned xch_opaque(unsigned off)
 #endif
     return off;
 }
-// The two words of a cell and field -- total and incident wave set -- are adjacent in memory and move together as ONE
-// 16-byte access (half the memory instructions, and the four border cells of a row become one full 64-byte line).
-// Each 8-byte half is still a self-validating (tag, value) word, so nothing depends on the 16 bytes arriving together.
-// Layout: [tag parity (2)][field of a set (6)][cell (P)][wave set (2)] 8-byte words.
-struct XchPair {
-    unsigned v0, t0, v1, t1;  // total: (value bits, tag), incident: (value bits, tag)
+struct XchG {
+    unsigned a, b, c, t;  // three value bit patterns, tag
 };
+constexpr int XCH_PLANES = 4;
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef unsigned int wv_u4 __attribute__((ext_vector_type(4)));
 // raw buffer resource over the exchange buffer (gfx9 word 3: 32-bit data format, raw addressing); accesses carry the
@@ -402,82 +419,155 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t xch_rsrc(const FusedParams &p)
     return __builtin_amdgcn_make_buffer_rsrc(p.xch, 0, (int)p.xch_bytes, 0x00020000);
 }
 #endif
-// byte offset of the plane of field `pl` (0..5) in the buffer of tag parity `par` (block-uniform)
-WV_HD unsigned xch_plane_offset(const FusedParams &p, unsigned par, int pl) { return (par * 6u + (unsigned)pl) * (p.P * 16u); }
-WV_HD void xch_put_pair(const FusedParams &p, unsigned plane_off, unsigned cell_off, float vt, float vi, unsigned tag)
+// byte offset of granule plane g (0..3) in the buffer of tag parity `par` (block-uniform); planes are P*16 bytes apart
+WV_HD unsigned xch_plane_offset(const FusedParams &p, unsigned par, int g) { return (par * (unsigned)XCH_PLANES + (unsigned)g) * (p.P * 16u); }
+WV_HD int xch_class(const FusedParams &p, bool lx, bool ly) { return p.reduced ? ((lx ? 1 : 0) | (ly ? 2 : 0)) : 3; }
+WV_HD void xch_put(const FusedParams &p, unsigned base, unsigned off, unsigned a, unsigned b, unsigned c, unsigned tag)
 {
-    const unsigned b0 = xch_copy(__builtin_bit_cast(unsigned, vt)), b1 = xch_copy(__builtin_bit_cast(unsigned, vi));
 #if defined(__HIP_DEVICE_COMPILE__)
-    const wv_u4 w = {b0, tag, b1, tag};
-    __builtin_amdgcn_raw_buffer_store_b128(w, xch_rsrc(p), (int)cell_off, (int)plane_off, 16);  // aux 16: sc1
+    // The three values are copied into the word's registers by hand (see xch_copy).  Wait states on both sides of the
+    // copies, because the compiler does not look into inline assembly -- and because its own model of this hazard says
+    // "none when the store has an SGPR soffset", which gfx950 does not honour for these sc1 stores:
+    //   * before: the registers may be the data registers of the 16-byte store issued just before (the previous granule).
+    //     A buffer store of more than 8 bytes reads its data some cycles after issue; overwriting them at once made lanes
+    //     12-15 of every 16 of the PREVIOUS store carry the NEW values (found with tools/debug_res.py: the total-set
+    //     granule arrived with the incident set's values in those lanes);
+    //   * after: a VALU write of a VGPR needs a wait state before a store of more than 8 bytes reads it.
+    unsigned o0, o1, o2;
+    asm volatile("s_nop 3\n\tv_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5\n\ts_nop 1"
+                 : "=&v"(o0), "=&v"(o1), "=&v"(o2)
+                 : "v"(a), "v"(b), "v"(c));
+    const wv_u4 w = {o0, o1, o2, tag};
+    __builtin_amdgcn_raw_buffer_store_b128(w, xch_rsrc(p), (int)off, (int)base, 16);  // aux 16: sc1
 #else
-    unsigned long long *q = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(p.xch) + plane_off + cell_off);
-    q[0] = ((unsigned long long)tag << 32) | b0;
-    q[1] = ((unsigned long long)tag << 32) | b1;
+    unsigned *q = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(p.xch) + base + off);
+    q[0] = a;
+    q[1] = b;
+    q[2] = c;
+    q[3] = tag;
 #endif
 }
-WV_HD XchPair xch_get_pair(const FusedParams &p, unsigned plane_off, unsigned cell_off)
+WV_HD void xch_putf(const FusedParams &p, unsigned base, unsigned off, float a, float b, float c, unsigned tag)
+{
+    xch_put(p, base, off, __builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, c), tag);
+}
+WV_HD XchG xch_get(const FusedParams &p, unsigned base, unsigned off)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const wv_u4 w = __builtin_amdgcn_raw_buffer_load_b128(xch_rsrc(p), (int)cell_off, (int)plane_off, 16);
-    return XchPair{w.x, w.y, w.z, w.w};
+    const wv_u4 w = __builtin_amdgcn_raw_buffer_load_b128(xch_rsrc(p), (int)off, (int)base, 16);
+    return XchG{w.x, w.y, w.z, w.w};
 #else
-    const unsigned long long *q =
-        reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(p.xch) + plane_off + cell_off);
-    return XchPair{(unsigned)q[0], (unsigned)(q[0] >> 32), (unsigned)q[1], (unsigned)(q[1] >> 32)};
+    const unsigned *q = reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(p.xch) + base + off);
+    return XchG{q[0], q[1], q[2], q[3]};
 #endif
+}
+// auxiliary field k (0 Psi_x, 1 Psi_y, 2 Omega) of one wave set of a cell, as the tile's field set holds it (0: not carried)
+template <int AUX>
+WV_HD float xch_aux_of(const float (&y)[aux_ns(AUX)], int k)
+{
+    if (AUX == AUX_PX) return k == 0 ? y[aux_ns(AUX) - 1] : 0.0f;
+    if (AUX == AUX_PY) return k == 1 ? y[aux_ns(AUX) - 1] : 0.0f;
+    if (AUX == AUX_ALL) return y[aux_ns(AUX) - 3 + k];
+    return 0.0f;
 }
 
-// Between two steps of a resident tile only y (the new state) is needed.  The stage code writes acc / px / u under
-// row conditions, which makes them look live around the whole step loop to the register allocator (a path that skips
-// the write reaches the next read); giving them a value on every path here ends those live ranges, so that the halo
-// poll -- which keeps all of a thread's exchange words in flight -- has the registers.
+// Between two steps of a resident tile only the state is carried: y (the new state) up to the halo poll, u after it.
+// The stage code writes acc / px / y under row conditions, which makes them look live around the whole step loop to the
+// register allocator (a path that skips the write reaches the next read).  Giving them an arbitrary value here ends
+// those live ranges without creating new ones (a frozen undefined value needs no register: zeros would have to be carried
+// around the loop), so that the halo poll -- which keeps all of a thread's exchange granules in flight -- has the registers.
+WV_HD float wv_any(float v)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(WV_NO_ANY)
+    return __builtin_nondeterministic_value(v);
+#else
+    return v * 0.0f;
+#endif
+}
 template <int AUX, int RPT>
-WV_HD void fused_end_step(FusedRegs<AUX, RPT> &r)
+WV_HD void fused_end_step(FusedRegs<AUX, RPT> &r)  // after stage 4 (y is still needed)
 {
     constexpr int NS = aux_ns(AUX);
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r.px[rr][k] = 0.0f;
+        for (int k = 0; k < 4; ++k) r.px[rr][k] = wv_any(r.px[rr][k]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) r.bsq[q][rr] = wv_any(r.bsq[q][rr]);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int j = 0; j < NS; ++j) r.acc[rr][s][j] = 0.0f;
+            for (int j = 0; j < NS; ++j) {
+                r.acc[rr][s][j] = wv_any(r.acc[rr][s][j]);
+                r.u[rr][s][j] = wv_any(r.u[rr][s][j]);
+            }
     }
 }
+template <int AUX, int RPT>
+WV_HD void fused_end_poll(FusedRegs<AUX, RPT> &r)  // after the halo poll (u holds the state)
+{
+    constexpr int NS = aux_ns(AUX);
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < NS; ++j) r.y[rr][s][j] = wv_any(r.y[rr][s][j]);
+}
 
-// after stage 4: the tile's output cells within FT_H of the edge of its output rectangle -> exchange buffer
+// after stage 4: the tile's output cells within FT_H of the edge of its output rectangle -> exchange buffer.
+// Rows of the top / bottom border: every own lane stores the granules of its cell.  Other own rows: only the 4 + 4
+// x-border cells go out.
 template <int AUX, int NW, int RPT>
 WV_HD void fused_xch_store(const FusedParams &p, unsigned tag, const TileDesc &t, int tid, const FusedRegs<AUX, RPT> &r)
 {
     constexpr int NS = aux_ns(AUX);
+    constexpr bool HAS_SY = AUX == AUX_PY || AUX == AUX_ALL;
     const int lane = tid & 63, w = tid >> 6;
-    if (lane < FT_H || lane >= FT_H + t.ox) return;
-    const bool ringx = lane < 2 * FT_H || lane >= t.ox;
     const int gx = t.x0 - FT_H + lane;
+    const bool ownx = lane >= FT_H && lane < FT_H + t.ox;
+    const bool bordx = ownx && (lane < 2 * FT_H || lane >= t.ox);
+    const bool lx = r.sx != 0.0f;
+    const unsigned PS = p.P * 16u;
+    const unsigned base = xch_plane_offset(p, tag & 1u, 0);
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
         const int ly = w + NW * rr;
         if (ly < FT_H || ly >= FT_H + t.oy) continue;
-        if (!(ringx || ly < 2 * FT_H || ly >= t.oy)) continue;
-#ifdef WV_XCH_NOXBORDER  // (timing experiment only: rows that only contribute their x-border are not sent)
-        if (!(ly < 2 * FT_H || ly >= t.oy)) continue;
-#endif
+        const bool rowb = ly < 2 * FT_H || ly >= t.oy;
         const int gy = t.y0 - FT_H + ly;
-        const unsigned off = ((unsigned)gy * (unsigned)p.nx + (unsigned)gx) * 16u;  // byte offset in a plane: 16*P < 2^32
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-#ifndef WV_XCH_NOSTORE  // (timing experiment only)
-            xch_put_pair(p, xch_plane_offset(p, tag & 1u, aux_plane(AUX, j)), off, r.y[rr][0][j], r.y[rr][1][j], tag);
-#endif
+        const unsigned row = (unsigned)gy * (unsigned)p.nx;
+        const unsigned off = (row + (unsigned)gx) * 16u;  // byte offset in a plane: 16*P < 2^32
+        const float(&y)[2][NS] = r.y[rr];
+        const bool mine = rowb ? ownx : bordx;
+#ifdef WV_XCH_NOSTORE  // (timing experiment only)
+        (void)off; (void)mine; (void)base; (void)PS; (void)lx;
+        continue;
+#else
+        if (mine) {
+            xch_putf(p, base, off, y[0][0], y[0][1], y[0][2], tag);
+            xch_putf(p, base + PS, off, y[1][0], y[1][1], y[1][2], tag);
         }
+        if (NS > 3) {
+            const bool lyy = HAS_SY ? p.sy[gy] != 0.0f : false;
+            const int cls = xch_class(p, lx, lyy);
+            if (mine && cls == 3) {
+                xch_putf(p, base + 2 * PS, off, xch_aux_of<AUX>(y[0], 0), xch_aux_of<AUX>(y[0], 1), xch_aux_of<AUX>(y[0], 2), tag);
+                xch_putf(p, base + 3 * PS, off, xch_aux_of<AUX>(y[1], 0), xch_aux_of<AUX>(y[1], 1), xch_aux_of<AUX>(y[1], 2), tag);
+            } else if (mine && cls != 0) {  // (selects, not a run-time index: the state must stay in registers)
+                const float vt = cls == 1 ? xch_aux_of<AUX>(y[0], 0) : xch_aux_of<AUX>(y[0], 1);
+                const float vi = cls == 1 ? xch_aux_of<AUX>(y[1], 0) : xch_aux_of<AUX>(y[1], 1);
+                xch_putf(p, base + 2 * PS, off, vt, vi, 0.0f, tag);
+            }
+        }
+#endif
     }
 }
 
 // Before the next step: u <- y on the tile's own cells, u <- the neighbours' border values on the halo ring.  Returns
-// false when some word of this thread's halo cells does not carry `tag` yet (the caller polls: nothing but r.u has been
-// modified, and every call rewrites all of it).
+// false when some granule of this thread's halo cells does not carry `tag` yet (the caller polls: nothing but r.u has
+// been modified, and every call rewrites all of it).  Halo rows: every lane loads the granules of its cell.  Own rows:
+// only the 4 + 4 halo lanes load anything.
 template <int AUX, int NW, int RPT>
 WV_HD bool fused_xch_load(const FusedParams &p, unsigned tag, const TileDesc &t, int tid, FusedRegs<AUX, RPT> &r)
 {
@@ -487,56 +577,88 @@ WV_HD bool fused_xch_load(const FusedParams &p, unsigned tag, const TileDesc &t,
     const bool inx = gx >= 0 && gx < p.nx && lane < t.ox + 2 * FT_H;  // (columns beyond the region belong to nobody's ring)
     const int cgx = gx < 0 ? 0 : (gx >= p.nx ? p.nx - 1 : gx);
     const bool ownx = lane >= FT_H && lane < FT_H + t.ox;
+    const bool lx = r.sx != 0.0f;
+    const unsigned PS = p.P * 16u;
+    const unsigned base = xch_plane_offset(p, tag & 1u, 0);
     bool ok = true;
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
         const int ly = w + NW * rr;
         const int gy = t.y0 - FT_H + ly;
-        const bool in = inx && gy >= 0 && gy < p.ny && ly < t.oy + 2 * FT_H;
+        const bool in_row = gy >= 0 && gy < p.ny && ly < t.oy + 2 * FT_H;
         const int cgy = gy < 0 ? 0 : (gy >= p.ny ? p.ny - 1 : gy);
-        const unsigned off = ((unsigned)cgy * (unsigned)p.nx + (unsigned)cgx) * 16u;
-        const bool own = ownx && ly >= FT_H && ly < FT_H + t.oy;
+        const bool rowown = ly >= FT_H && ly < FT_H + t.oy;
+        const bool own = ownx && rowown;
 #ifdef WV_XCH_NOLOAD  // (timing experiment only: no halo is read at all)
-        const bool need = false && in;
+        const bool need = false && inx && in_row;
 #else
-        const bool need = in && !own;
+        const bool need = inx && in_row && !own;
 #endif
-        // With reduced field sets the owner of a halo cell carries -- and sends -- an auxiliary field only where that
-        // field can be non-zero (Psi_x: sigma_x != 0 in the column, Psi_y: sigma_y != 0 in the row, Omega: both); anywhere
-        // else its value is the exact zero the field-set invariant guarantees, and there is no word to wait for.
-        bool needj[NS];
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            const int pl = aux_plane(AUX, j);
-            bool live = true;
-            if (p.reduced && pl >= 3) {
-                const bool lx = r.sx != 0.0f, ly_ = p.sy[cgy] != 0.0f;
-                live = pl == 3 ? lx : (pl == 4 ? ly_ : (lx && ly_));
-            }
-            needj[j] = need && live;
-        }
-        XchPair wd[NS];
-#pragma unroll
-        for (int j = 0; j < NS; ++j) wd[j] = XchPair{0u, 0u, 0u, 0u};
-        if (need) {  // one divergent region per row; the offsets are formed right here (uniform base + 32-bit offset)
+        const unsigned row = (unsigned)cgy * (unsigned)p.nx;
+        const unsigned off = (row + (unsigned)cgx) * 16u;
+        XchG g0{0u, 0u, 0u, tag}, g1{0u, 0u, 0u, tag};
+        if (need) {
             const unsigned o = xch_opaque(off);
-#pragma unroll
-            for (int j = 0; j < NS; ++j)
-                if (needj[j]) wd[j] = xch_get_pair(p, xch_plane_offset(p, tag & 1u, aux_plane(AUX, j)), o);
+            g0 = xch_get(p, base, o);
+            g1 = xch_get(p, base + PS, o);
         }
+#ifndef WV_XCH_NOWAIT  // (timing experiment only: results are wrong without the check)
+        ok = ok && g0.t == tag && g1.t == tag;
+#endif
+        float at[3] = {0.0f, 0.0f, 0.0f}, ai[3] = {0.0f, 0.0f, 0.0f};  // Psi_x, Psi_y, Omega of the halo cell
+        if (AUX == AUX_PX || AUX == AUX_PY) {
+            // one auxiliary field (these tiles only exist with reduced field sets, and their region has sigma == 0 along
+            // the other axis): the halo cell sends it -- in a class 1 / class 2 granule -- where it can be non-zero
+            const bool live = AUX == AUX_PX ? lx : p.sy[cgy] != 0.0f;
+            XchG h2{0u, 0u, 0u, tag};
+            if (need && live) h2 = xch_get(p, base + 2 * PS, xch_opaque(off));
+#ifndef WV_XCH_NOWAIT
+            ok = ok && h2.t == tag;
+#endif
+            at[AUX == AUX_PX ? 0 : 1] = __builtin_bit_cast(float, xch_copy(h2.a));
+            ai[AUX == AUX_PX ? 0 : 1] = __builtin_bit_cast(float, xch_copy(h2.b));
+        } else if (AUX == AUX_ALL) {
+            // With reduced field sets the owner of a halo cell carries -- and sends -- an auxiliary field only where that
+            // field can be non-zero; anywhere else its value is the exact zero the field-set invariant guarantees.
+            const int cls = xch_class(p, lx, p.sy[cgy] != 0.0f);
+            XchG h2{0u, 0u, 0u, tag}, h3{0u, 0u, 0u, tag};
+            if (need && cls != 0) {
+                const unsigned o = xch_opaque(off);
+                h2 = xch_get(p, base + 2 * PS, o);
+                if (cls == 3) h3 = xch_get(p, base + 3 * PS, o);
+            }
+#ifndef WV_XCH_NOWAIT
+            ok = ok && h2.t == tag && h3.t == tag;
+#endif
+            // (selects, not run-time indices: everything stays in registers)
+            const float a2 = __builtin_bit_cast(float, xch_copy(h2.a)), b2 = __builtin_bit_cast(float, xch_copy(h2.b));
+            const float c2 = __builtin_bit_cast(float, xch_copy(h2.c));
+            const float a3 = __builtin_bit_cast(float, xch_copy(h3.a)), b3 = __builtin_bit_cast(float, xch_copy(h3.b));
+            const float c3 = __builtin_bit_cast(float, xch_copy(h3.c));
+            at[0] = (cls & 1) ? a2 : 0.0f;
+            ai[0] = cls == 3 ? a3 : (cls == 1 ? b2 : 0.0f);
+            at[1] = cls == 3 ? b2 : (cls == 2 ? a2 : 0.0f);
+            ai[1] = cls == 3 ? b3 : (cls == 2 ? b2 : 0.0f);
+            at[2] = cls == 3 ? c2 : 0.0f;
+            ai[2] = cls == 3 ? c3 : 0.0f;
+        }
+#ifdef WV_XCH_DEBUG
+        if (need && !(g0.t == tag && g1.t == tag) && wv_xch_debug)
+            printf("  slot %d aux %d x0 %d y0 %d ox %d oy %d: lane %d ly %d gx %d gy %d has tags %u %u want %u\n", t.slot, t.aux, t.x0, t.y0, t.ox, t.oy, lane, ly, gx, gy, g0.t, g1.t, tag), wv_xch_debug--;
+#endif
+        const unsigned v0[3] = {g0.a, g0.b, g0.c}, v1[3] = {g1.a, g1.b, g1.c};
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             float vt = own ? r.y[rr][0][j] : 0.0f, vi = own ? r.y[rr][1][j] : 0.0f;
-            if (needj[j]) {
-#ifdef WV_XCH_DEBUG
-                if ((wd[j].t0 != tag || wd[j].t1 != tag) && wv_xch_debug)
-                    printf("  slot %d aux %d x0 %d y0 %d ox %d oy %d: lane %d ly %d gx %d gy %d plane %d has tags %u %u want %u\n", t.slot, t.aux, t.x0, t.y0, t.ox, t.oy, lane, ly, gx, gy, aux_plane(AUX, j), wd[j].t0, wd[j].t1, tag), wv_xch_debug--;
-#endif
-#ifndef WV_XCH_NOWAIT  // (timing experiment only: results are wrong without the check)
-                ok = ok && wd[j].t0 == tag && wd[j].t1 == tag;
-#endif
-                vt = __builtin_bit_cast(float, xch_copy(wd[j].v0));
-                vi = __builtin_bit_cast(float, xch_copy(wd[j].v1));
+            if (need) {
+                if (j < 3) {
+                    vt = __builtin_bit_cast(float, xch_copy(v0[j]));
+                    vi = __builtin_bit_cast(float, xch_copy(v1[j]));
+                } else {
+                    const int k = aux_plane(AUX, j) - 3;
+                    vt = at[k];
+                    vi = ai[k];
+                }
             }
             r.u[rr][0][j] = vt;
             r.u[rr][1][j] = vi;

@@ -2,6 +2,8 @@
 // Pure C++ (no HIP), shared by kernels_fused.hip and the CPU emulation harness in tests/cpu_emu.
 #pragma once
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <utility>
@@ -261,12 +263,24 @@ inline void plan_pair_order(HostPlan &pl, int pair_cus)
 {
     const int n = (int)pl.tiles.size();
     if (!(pair_cus > 0 && pl.band_begin.size() == 2 && n > pair_cus && n <= 2 * pair_cus)) return;
+    // relative cost of a tile: field set x rows in use x cylinders evaluated x boundary code.  WAVES_AMD_PAIR_W
+    // ("px,py,all,cyl1,cylk,edge") overrides the factors (tuning runs).
+    static double W[6] = {1.22, 1.22, 1.75, 1.6, 0.2, 1.0};
+    static bool parsed = false;
+    if (!parsed) {
+        parsed = true;
+        if (const char *e = getenv("WAVES_AMD_PAIR_W")) {
+            double v[6];
+            if (sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) == 6)
+                for (int k = 0; k < 6; ++k) W[k] = v[k];
+        }
+    }
     auto weight = [&](const TileDesc &t) {
         const int RY = t.aux == AUX_NONE ? pl.RYF : (t.aux == AUX_ALL ? pl.RYP : pl.RYB);
         const double fill = (double)(t.oy + 2 * FT_H) / RY;
-        const double set = t.aux == AUX_NONE ? 1.0 : (t.aux == AUX_ALL ? 1.75 : 1.22);
+        const double set = t.aux == AUX_NONE ? 1.0 : (t.aux == AUX_ALL ? W[2] : (t.aux == AUX_PX ? W[0] : W[1]));
         const int nc = t.cyl_count < 0 ? 8 : t.cyl_count;
-        return fill * set * (nc > 0 ? 1.6 + 0.2 * (nc - 1) : 1.0);
+        return fill * set * (nc > 0 ? W[3] + W[4] * (nc - 1) : 1.0) * (t.edge ? W[5] : 1.0);
     };
     std::vector<std::pair<double, int>> key(n);  // (−weight, position): ascending sort = heaviest first, ties in order
     for (int i = 0; i < n; ++i) key[i] = {-weight(pl.tiles[i]), i};

@@ -19,6 +19,31 @@ namespace wv {
 
 namespace {
 
+// The step loop must compile like a sequence of single-step bodies: only the tile's registers are carried from one
+// step to the next.  Left alone, the compiler hoists every loop-invariant load, index and address out of the loop and
+// keeps them live across it (hundreds of spills); so each iteration starts from values the optimiser cannot see through.
+// (the pointers keep their address space -- constant: kernarg segment / tables nobody writes during the launch -- so
+// that what is loaded through them stays scalar loads, and the pointers found there global rather than flat)
+template <class T>
+__device__ __forceinline__ const T *opaque(const T *p)
+{
+    auto q = (const __attribute__((address_space(4))) T *)p;
+    asm volatile("" : "+s"(q));
+    return (const T *)q;
+}
+__device__ __forceinline__ int opaque(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// The tile descriptor of this block, through scalar loads (the table is written by the host before the launch and by
+// nobody during it; left to itself the compiler fetches it with vector loads -- a memory round trip in front of everything)
+__device__ __forceinline__ TileDesc load_tile(const FusedParams &p)
+{
+    return opaque(p.tiles)[p.tile_offset + (int)blockIdx.x];
+}
+
 template <int AUX, int FL, int NW, int RPT, int RYMAX>
 __device__ __forceinline__ void run_tile(const FusedParams &p, const TileDesc &t, F2 *raw, float e[3])
 {
@@ -84,7 +109,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_step_fused(FusedParams p_)  // 4
     constexpr int RYMAX = NW * RMAX;
     __shared__ F2 raw[lds_elems(RYMAX)];
     __shared__ float red[3][NW];
-    const TileDesc t = p.tiles[p.tile_offset + blockIdx.x];
+    const TileDesc t = load_tile(p);
     float e[3];
     // smallest instantiated superset of the features this tile needs (block-uniform dispatch): boundary tiles are
     // specialised per side (left/right strips, bottom/top bands), corners get all four sides
@@ -148,24 +173,6 @@ __global__ __launch_bounds__(NW * 64, 4) void k_step_fused(FusedParams p_)  // 4
 // host reports the failure.
 constexpr int WV_WAIT_POLLS = 1 << 20;  // default of FusedParams::max_polls (WAVES_AMD_WAIT_POLLS overrides: tests)
 
-// The step loop must compile like a sequence of single-step bodies: only the tile's registers are carried from one
-// step to the next.  Left alone, the compiler hoists every loop-invariant load, index and address out of the loop and
-// keeps them live across it (hundreds of spills); so each iteration starts from values the optimiser cannot see through.
-// (the pointers keep their address space -- constant: kernarg segment / tables nobody writes during the launch -- so
-// that what is loaded through them stays scalar loads, and the pointers found there global rather than flat)
-template <class T>
-__device__ __forceinline__ const T *opaque(const T *p)
-{
-    auto q = (const __attribute__((address_space(4))) T *)p;
-    asm volatile("" : "+s"(q));
-    return (const T *)q;
-}
-__device__ __forceinline__ int opaque(int v)
-{
-    asm volatile("" : "+v"(v));
-    return v;
-}
-
 // barrier that orders LDS accesses only (__syncthreads also waits for every outstanding global access)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -177,7 +184,7 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
     TileCtx cx;
     {
         const FusedParams &p = *opaque(p0);
-        const TileDesc t = p.tiles[p.tile_offset + blockIdx.x];
+        const TileDesc t = load_tile(p);
         const int tid = opaque((int)threadIdx.x);
         fused_tile_init<AUX, FL, NW, RPT>(p, t, tid, cx, r);
         fused_cyl_commit<FL>(t, tid, lds, cx, fused_cyl_fetch<AUX, FL, RPT>(p, 0, t, tid, cx, r));  // steps[s].step == s
@@ -186,7 +193,7 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
     }
     for (int s = 0;; ++s) {
         const FusedParams &p = *opaque(p0);
-        const TileDesc t = p.tiles[p.tile_offset + blockIdx.x];
+        const TileDesc t = load_tile(p);
         const int tid = opaque((int)threadIdx.x);
         const StepIO &io = opaque(p.steps)[s];
         // diagnostic stamps of ONE step (the middle one); p.stamps == nullptr in every normal run
@@ -261,6 +268,9 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
         const Cyl nc = fused_cyl_fetch<AUX, FL, RPT>(p, io.step + 1, t, tid, cx, r);
         bool ok = false;
         int polls = 0;
+#ifdef WV_POLL_DELAY  // (tuning experiment: the first poll is held back)
+        __builtin_amdgcn_s_sleep(WV_POLL_DELAY);
+#endif
         for (; polls < p.max_polls; ++polls) {
             ok = __all(fused_xch_load<AUX, NW, RPT>(p, tag, t, tid, r));
             if (ok) break;
@@ -273,6 +283,22 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
             *vote = 1;
         }
         fused_cyl_commit<FL>(t, tid, lds, cx, nc);
+#ifdef WV_XCH_VERIFY  // (diagnostic: a second read of the halo must return the very same values)
+        {
+            FusedRegs<AUX, RPT> r2 = r;
+            (void)fused_xch_load<AUX, NW, RPT>(p, tag, t, tid, r2);
+            int diff = 0;
+#pragma unroll
+            for (int rr = 0; rr < RPT; ++rr)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < aux_ns(AUX); ++j)
+                        diff += __builtin_bit_cast(unsigned, r2.u[rr][q][j]) != __builtin_bit_cast(unsigned, r.u[rr][q][j]) ? 1 : 0;
+            if (ok && diff) atomicAdd(p.abort + 1, diff);
+        }
+#endif
+        fused_end_poll<AUX, RPT>(r);
         // (nothing of the next step is scheduled into the poll: it would stretch the live ranges of the exchange words
         // over the publish phase and spill)
         asm volatile("s_nop 0" ::: "memory");
@@ -301,7 +327,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_steps_resident(FusedParams p_)
     __shared__ F2 raw[lds_elems(RYMAX)];
     __shared__ float red[3][NW];
     __shared__ int vote[1];  // a wave of the block gave up waiting for its halo
-    const TileDesc t = p.tiles[p.tile_offset + blockIdx.x];
+    const TileDesc t = load_tile(p);
 #define RUN(A, F, R) run_tile_resident<A, F, NW, R, RYMAX>(&p, raw, red, vote)
     const int fl = tile_flags(p, t);
     const int fe = fl & F_EDGE;
@@ -424,7 +450,7 @@ struct FusedPlan {
     StepIO *d_steps = nullptr;
     size_t steps_cap = 0;
     std::vector<StepIO> h_steps;  // what d_steps holds
-    unsigned long long *d_xch = nullptr;  // tagged halo exchange buffer [2][12][P], see fused_xch_*
+    unsigned long long *d_xch = nullptr;  // tagged halo exchange buffer: [2 parities][4 planes][P] granules of 16 bytes, see fused_xch_*
     unsigned tag_base = 0;        // tags handed out so far (the buffer never holds a tag above it)
     unsigned tag_base_init = 0;   // diagnostic: first tag base after the buffer is created
     int *d_abort = nullptr;
@@ -459,9 +485,9 @@ FusedPlan *fused_create(const Grid &g, const float *x, const float *y, const flo
     if (const char *e = getenv("WAVES_AMD_FUSED_GRAPH")) p->use_graph = atoi(e) != 0;
     if (const char *e = getenv("WAVES_AMD_FUSED_RESIDENT")) p->use_resident = atoi(e) != 0;
     if (const char *e = getenv("WAVES_AMD_TAG_BASE")) p->tag_base_init = (unsigned)strtoul(e, nullptr, 0);  // tests: wrap
-    if (hipMalloc((void **)&p->d_flag, sizeof(int)) != hipSuccess || hipMalloc((void **)&p->d_abort, sizeof(int)) != hipSuccess ||
+    if (hipMalloc((void **)&p->d_flag, sizeof(int)) != hipSuccess || hipMalloc((void **)&p->d_abort, 4 * sizeof(int)) != hipSuccess ||
         hipHostMalloc((void **)&p->h_abort, sizeof(int), hipHostMallocDefault) != hipSuccess ||
-        hipMemset(p->d_abort, 0, sizeof(int)) != hipSuccess) {
+        hipMemset(p->d_abort, 0, 4 * sizeof(int)) != hipSuccess) {
         fused_destroy(p);
         return nullptr;
     }
@@ -718,7 +744,7 @@ int fused_try_resident(FusedPlan *pl, const FusedCall &call, const FusedStep *st
     if (nsteps < 2 || (int)nt > resident_capacity(pl)) return -1;
     // exchange buffer: zeroed once (tag 0 is never expected); tags only grow, so words of earlier calls -- or of an
     // earlier tile decomposition -- can never be mistaken for the ones a step waits for
-    const size_t xwords = (size_t)2 * 12 * pl->g.P;
+    const size_t xwords = (size_t)2 * XCH_PLANES * 2 * pl->g.P;  // 8-byte words: 2 parities x 4 planes x P granules of 16 bytes
     if (!pl->d_xch || pl->tag_base > 0xFFFF0000u - (unsigned)nsteps) {
         if (!pl->d_xch && hipMalloc((void **)&pl->d_xch, xwords * sizeof(unsigned long long)) != hipSuccess) {
             (void)hipGetLastError();
@@ -778,6 +804,14 @@ int fused_try_resident(FusedPlan *pl, const FusedCall &call, const FusedStep *st
 
 int fused_finish(FusedPlan *pl, hipStream_t s)
 {
+#ifdef WV_XCH_VERIFY
+    {
+        int v[4] = {0, 0, 0, 0};
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(v, pl->d_abort, sizeof(v), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[waves_amd verify] halo values that changed between two successful reads so far: %d\n", v[1]);
+    }
+#endif
     if (!pl->abort_pending) return 0;
     pl->abort_pending = false;
     if (*pl->h_abort == 0) return 0;
