@@ -10,9 +10,11 @@ wave-speed field assembly, source injection, energy reductions and frame capture
 resident in HBM when the timed region starts (the only host->device traffic per action is the ~100 KB coefficient
 table; the only device->host traffic is the 101x3 energy trace).
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), each rank runs its own environment (weak scaling:
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), each rank runs its own environment(s) (weak scaling:
 independent episodes); the design-space block is broadcast from rank 0 before the timed region and the
-energy traces are all-gathered after the last step inside it.
+energy traces are all-gathered after the last step inside it.  Launched either by torch.distributed.run (RANK /
+LOCAL_RANK / WORLD_SIZE in the environment) or plainly as `python bench.py --gpus N`, which starts the N ranks itself.
+`--envs-per-gpu 8` is BASELINE config 3's shape (64 episodes on 8 GPUs); `--steps 20` config 5's rollout length.
 
 Prints ONE JSON line on rank 0.
 """
@@ -125,6 +127,93 @@ def batched_envs(w, dim, ds, dev, impl, n_envs, pml_width, actions=6):
                     "not the headline"}
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (this parent never touches a
+    GPU, so nothing that initialised HIP is ever replaced), relay rank 0's JSON line, exit with the worst return code."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for pr in procs[1:]:
+        rc = max(rc, abs(pr.wait()))
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    return rc
+
+
+def make_env(w, dim, ds, dev, impl, pml_width, actions, seed, **kw):
+    src = w.RandomPosGaussianSource(w.build_grid(dim), [[-10.0, -10.0]], [[-10.0, 10.0]], [0.3], [1.0], 1000.0,
+                                    rng=np.random.default_rng(2 + seed))
+    env = w.WaveEnv(dim, design_space=ds, source=src, integration_steps=STEPS_PER_ACTION, actions=actions, device=dev,
+                    impl=impl, rng=np.random.default_rng(seed), return_fields=False, pml_width=pml_width, **kw)
+    policy = w.RandomDesignPolicy(env.action_space(), np.random.default_rng(1 + seed))
+    env.reset()
+    return env, policy
+
+
+def timed_rollout(env, policy, n_actions):
+    """n_actions x env(policy(env)) with two actions in flight (w.rollout_pipelined spelled out to collect the timings)."""
+    sigs, kern_ms, launches, dev_ms = [], 0.0, 0, 0.0
+
+    def end():
+        nonlocal kern_ms, launches, dev_ms
+        env.step_end()
+        sigs.append(env.signal)
+        t = env.ctx.timing()
+        kern_ms += t["step_kernel_ms"]
+        launches += t["step_kernel_launches"]
+        dev_ms += t["total_ms"]
+
+    for k in range(n_actions):
+        env.step_begin(policy(env))
+        if k > 0:
+            end()
+    end()
+    return sigs, kern_ms, launches, dev_ms
+
+
+def side_config(w, ds, dev, impl, grid, pml_width, actions, traffic_tab):
+    """One more BASELINE configuration size measured in the same process after the headline (never `value`)."""
+    import torch
+    dim = w.TwoDim(15.0, grid)
+    env, policy = make_env(w, dim, ds, dev, impl, pml_width, actions + 6, 9000 + grid)
+    for _ in range(2):
+        env(policy(env))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, kern_ms, launches, _ = timed_rollout(env, policy, actions)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tim = env.ctx.timing()
+    resident = bool(tim["resident"])
+    cells = grid * grid
+    units = cells * (STEPS_PER_ACTION if resident else 1)
+    avg_ms = kern_ms / max(launches, 1)
+    key = ("resident" if resident else tim["impl"]) + ("" if grid == N_GRID else f"_{grid}")
+    env.ctx.close()
+    return {"workload": f"TwoDim(15.0f0, {grid}) + triple-ring design_space, pml_width {pml_width}, {actions} actions x "
+                        f"{STEPS_PER_ACTION} steps", "kernel": "k_steps_resident" if resident else "k_step_fused",
+            "value": round(actions * STEPS_PER_ACTION * cells / dt / 1e6, 2), "unit": "Mcell-updates/s",
+            "avg_kernel_us": round(avg_ms * 1e3, 3), "steps_per_launch": STEPS_PER_ACTION if resident else 1,
+            "frac": round(B_ALG * units / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "whole_job_frac": round(B_ALG * actions * STEPS_PER_ACTION * cells / dt / (HBM_PEAK_GBS * 1e9), 4),
+            "traffic": traffic_tab.get(key) if (grid == N_GRID or pml_width == 2.0) else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,10 +223,16 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=40, help="integration steps of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--grid", type=int, default=N_GRID, help="grid points per axis (700 = the metric's configuration)")
     ap.add_argument("--pml-width", type=float, default=2.0)
+    ap.add_argument("--envs-per-gpu", type=int, default=1,
+                    help="independent environments per rank (BASELINE config 3: 8 per GPU, stepped four at a time on their "
+                         "HIP streams); 1 = the headline: one environment, two of its actions in flight")
     ap.add_argument("--batch-envs", type=int, default=8,
-                    help="extra (untimed-for-`value`) measurement: this many independent envs on the GPU, BASELINE config "
-                         "3's 8-per-GPU shape, stepped four at a time on their HIP streams (0 = skip)")
+                    help="extra (untimed-for-`value`) measurement at N=1: this many independent envs on the GPU (0 = skip)")
+    ap.add_argument("--side-configs", type=int, default=1, help="N=1: also time 2048^2 and 256^2 after the headline (0 = skip)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch  # first: the HIP runtime both torch and libwaves_amd use is then torch's
     import waves_jl_amd as w
@@ -146,31 +241,46 @@ def main():
     rank, local_rank, world = wd.init()
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
     ngrid = args.grid
-    dev = local_rank if torch.cuda.device_count() > local_rank else 0
-    torch.cuda.set_device(dev)
+    ndev = torch.cuda.device_count()
+    if ndev > 0 and local_rank >= ndev:
+        # several ranks on one GPU cannot all hold the device for the cooperative resident kernel: rehearsals only
+        if not os.environ.get("WAVES_AMD_ALLOW_SHARED_GPU"):
+            print(f"bench.py: rank {rank} has no GPU of its own ({ndev} visible); set WAVES_AMD_ALLOW_SHARED_GPU=1 to "
+                  "rehearse with ranks sharing a device (single-step kernels)", file=sys.stderr)
+            sys.exit(2)
+        os.environ["WAVES_AMD_FUSED_RESIDENT"] = "0"
+    dev = local_rank % max(ndev, 1)
+    if ndev > 0:
+        torch.cuda.set_device(dev)
 
-    # --- environment: rank 0 owns the design-space block, everyone else receives it over RCCL
+    # --- environments: rank 0 owns the design-space block, everyone else receives it over RCCL
     ds = w.build_triple_ring_design_space() if rank == 0 else None
     ds = wd.broadcast_design_space(ds, src=0)
     dim = w.TwoDim(15.0, ngrid)
-    src = w.RandomPosGaussianSource(w.build_grid(dim), [[-10.0, -10.0]], [[-10.0, 10.0]], [0.3], [1.0], 1000.0,
-                                    rng=np.random.default_rng(2 + 1000 * rank))
+    E = max(1, args.envs_per_gpu)
     total_actions = args.warmup + args.steps
-    env = w.WaveEnv(dim, design_space=ds, source=src, integration_steps=STEPS_PER_ACTION, actions=total_actions + 8,
-                    device=dev, impl=args.impl, rng=np.random.default_rng(1000 * rank), return_fields=False,
-                    pml_width=args.pml_width)
-    policy = w.RandomDesignPolicy(env.action_space(), np.random.default_rng(1 + 1000 * rank))
-    env.reset()
+    envs, pols = [], []
+    for e in range(E):
+        env, pol = make_env(w, dim, ds, dev, args.impl, args.pml_width, total_actions + 8, 1000 * rank + 17 * e)
+        envs.append(env)
+        pols.append(pol)
+    env, policy = envs[0], pols[0]
+
+    def sweep():
+        return w.step_all(envs, [pol(en) for en, pol in zip(envs, pols)])
 
     for _ in range(args.warmup):
-        env(policy(env))
+        if E == 1:
+            env(policy(env))
+        else:
+            sweep()
     if world > 1:
         wd.gather_signals(env.signal)  # warm the communicator up outside the timed region
     # A full collection of the interpreter's cyclic GC takes 30-50 ms once torch is imported (millions of objects) and
-    # would land in the middle of a 1.3 ms action every few hundred allocations: park everything allocated so far in the
+    # would land in the middle of a 1 ms action every few hundred allocations: park everything allocated so far in the
     # permanent generation, as long-running Python services do.
     gc.collect()
     gc.freeze()
@@ -178,33 +288,36 @@ def main():
     wd.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    sigs = []
     dev_ms = 0.0
     kern_ms, kern_launches = 0.0, 0
-    for _ in range(args.steps):
-        env(policy(env))
-        sigs.append(env.signal)
-        tim_ = env.ctx.timing()
-        dev_ms += tim_["total_ms"]
-        kern_ms += tim_["step_kernel_ms"]
-        kern_launches += tim_["step_kernel_launches"]
+    if E == 1:
+        sigs, kern_ms, kern_launches, dev_ms = timed_rollout(env, policy, args.steps)
+    else:
+        sigs = []
+        for _ in range(args.steps):
+            sweep()
+            sigs.append(np.stack([en.signal for en in envs]))
+            for en in envs:
+                t_ = en.ctx.timing()
+                dev_ms += t_["total_ms"]
+                kern_ms += t_["step_kernel_ms"]
+                kern_launches += t_["step_kernel_launches"]
     all_sig = wd.gather_signals(np.stack(sigs))
     torch.cuda.synchronize()
     wd.barrier()
     elapsed = wd.max_over_ranks(time.perf_counter() - t0)
 
     cells = ngrid * ngrid
-    cell_updates = world * cells * STEPS_PER_ACTION * args.steps
+    cell_updates = world * E * cells * STEPS_PER_ACTION * args.steps
     value = cell_updates / elapsed / 1e6
 
     # --- roofline of the dominant kernel.  Its average launch duration is measured live with the HIP events the library
-    # records on the ctx's stream around every wv_integrate call of the TIMED region above (first enqueue -> last kernel),
-    # divided by the number of integrator launches in it:
+    # records on the ctx's stream directly around the integrator launch(es) of every wv_integrate call of the TIMED region
+    # above, divided by the number of integrator launches in it:
     #   * resident path (the default whenever all tiles fit the device at once, e.g. 700^2): ONE launch of
-    #     k_steps_resident per action does all 100 steps, so a launch processes 100 x cells cell-updates; the events sit
-    #     directly around that launch;
-    #   * single-step path (larger grids): 100 back-to-back k_step_fused launches per action between one pair of events,
-    #     gaps included; agrees with the rocprofv3 kernel-trace average to ~2 %.
+    #     k_steps_resident per action does all 100 steps, so a launch processes 100 x cells cell-updates;
+    #   * single-step path (larger grids, several envs per GPU): 100 back-to-back k_step_fused launches per action between
+    #     one pair of events, gaps included; agrees with the rocprofv3 kernel-trace average to ~2 %.
     # The event pair(s) placed directly around the integrator launch(es) (profiling mode) are reported for reference.
     out = None
     if rank == 0:
@@ -212,10 +325,10 @@ def main():
         impl = tim["impl"]
         resident = bool(tim.get("resident"))
         launches_per_action = 1 if resident else STEPS_PER_ACTION * (4 if impl == "staged" else 1)
-        if kern_launches > 0 and kern_ms > 0.0:   # fused path: events directly around the integrator launch(es)
+        if kern_launches > 0 and kern_ms > 0.0 and impl == "fused":   # events directly around the integrator launch(es)
             avg_ms = kern_ms / kern_launches
         else:                                      # staged path: whole call / launches
-            avg_ms = dev_ms / (args.steps * launches_per_action)
+            avg_ms = dev_ms / (args.steps * E * launches_per_action)
         env.ctx.set_profiling(True)
         kms, launches = 0.0, 0
         for _ in range(2):
@@ -231,14 +344,16 @@ def main():
             units_per_launch = cells if impl == "fused" else cells / 4.0   # staged: one RK stage = 1/4 cell-update per cell
         alg_bytes = B_ALG * units_per_launch
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_tab = None, {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and (ngrid == N_GRID or (ngrid == 2048 and args.pml_width == 2.0)):
+        if os.path.exists(tpath):
             try:
-                key = "resident" if resident else impl
-                traffic = json.load(open(tpath)).get(key if ngrid == N_GRID else f"{key}_{ngrid}")
+                traffic_tab = json.load(open(tpath))
             except Exception:
-                traffic = None
+                traffic_tab = {}
+        if ngrid == N_GRID or (ngrid == 2048 and args.pml_width == 2.0):
+            key = "resident" if resident else impl
+            traffic = traffic_tab.get(key if ngrid == N_GRID else f"{key}_{ngrid}")
         kname = "k_steps_resident" if resident else ("k_step_fused" if impl == "fused" else "k_stage")
         out = {
             "metric": baseline_metric(),
@@ -255,19 +370,32 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"TwoDim(15.0f0, {ngrid}) + triple-ring design_space, RandomPosGaussianSource, "
                                    f"{STEPS_PER_ACTION} integration steps per env action, RandomDesignPolicy",
-                       "impl": impl, "envs_per_gpu": 1, "pml_width": args.pml_width,
+                       "impl": impl, "envs_per_gpu": E, "pml_width": args.pml_width,
+                       "in_flight": "2 actions of the one env (host work of action k+1 under the kernel of action k)"
+                                    if E == 1 else "4 envs at a time on their HIP streams",
                        "device_ms_per_step": round(dev_ms / args.steps, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kname,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": "profiles/traffic.json: rocprofv3 PMC bytes per launch of this kernel, collected "
+                                           "by tools/collect_profiles.sh in a separate run (replayed here, not measured live)"
+                                           if traffic is not None else None,
+                         "kernel": kname,
                          "avg_kernel_us": round(avg_ms * 1e3, 3), "event_bracketed_kernel_us": round(bracketed_us, 3),
                          "algorithmic_bytes_per_launch": alg_bytes, "steps_per_launch": STEPS_PER_ACTION if resident else 1,
                          "whole_job_frac": round(B_ALG * value * 1e6 / world / (HBM_PEAK_GBS * 1e9), 4)},
             "signal_checksum": float(np.sum(all_sig[0][-1])),
         }
-        if world == 1 and args.batch_envs > 1:
+        if world == 1 and args.side_configs and ngrid == N_GRID and E == 1:
+            for en in envs:  # (a context takes the resident path only when it has the device to itself)
+                en.ctx.close()
+            out["configs"] = {"config4_2048_w2": side_config(w, ds, dev, args.impl, 2048, 2.0, 3, traffic_tab),
+                              "config1_size_256": side_config(w, ds, dev, args.impl, 256, 2.0, 10, traffic_tab)}
+        if world == 1 and args.batch_envs > 1 and E == 1:
             out["batched"] = batched_envs(w, dim, ds, dev, args.impl, args.batch_envs, args.pml_width)
         if world == 1 and args.cpu_steps > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
+    for en in envs:   # explicit: nothing is left for destructors that would run while the process (or a profiler) shuts down
+        en.ctx.close()
     wd.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)

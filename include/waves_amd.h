@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WV_ABI_VERSION 1
+#define WV_ABI_VERSION 2
 #define WV_NFIELDS 12 /* src/dynamics.jl:185-187 */
 #define WV_NFRAMES 3  /* src/env.jl:54,116 */
 #define WV_FRAMESKIP 10 /* src/env.jl:90 */
@@ -158,8 +158,13 @@ int wv_integrate(wv_ctx *ctx, const float *tspan, int nsteps, int capture_frames
  * nsteps + 1).  The 396 MB device-to-host copy of a 700^2 action shrinks by k; signal and frames are unaffected. */
 int wv_set_trajectory_stride(wv_ctx *ctx, int stride);
 
-/* The same split in two so that several ctxs on one device overlap: _begin enqueues all device work and returns,
- * _end waits and copies the outputs.  Exactly one _end per _begin. */
+/* The same split in two: _begin enqueues all device work and returns, _end waits and copies the outputs.  Exactly one
+ * _end per _begin.  Two uses: several ctxs on one device overlap (begin on all, then end on all); and ONE ctx may have
+ * two calls in flight -- begin(k+1) may be called before end(k), the host then prepares call k+1 (coefficient tables,
+ * tile culling, uploads on a copy stream) while call k runs, and only the device state is sequentially dependent (the
+ * reference's loop `env(policy(env))`, src/data.jl:22-27, with a policy that does not read the wave state).  _end ends
+ * the OLDEST pending call.  A second call is refused (WV_ERR_STATE) when either call returns trajectories or profiling
+ * is on; wv_set_design is the only setter allowed while a call is pending (it describes the NEXT call). */
 int wv_integrate_begin(wv_ctx *ctx, const float *tspan, int nsteps, int capture_frames, int want_signal,
                        int want_fields);
 int wv_integrate_end(wv_ctx *ctx, float *signal, float *u_tot, float *u_inc);
@@ -169,8 +174,17 @@ int wv_set_profiling(wv_ctx *ctx, int on); /* bracket every step kernel with HIP
 int wv_get_timing(wv_ctx *ctx, wv_timing *out);
 int wv_set_stream(wv_ctx *ctx, void *hip_stream); /* run on a caller-owned hipStream_t (NULL: back to the ctx's own) */
 int wv_synchronize(wv_ctx *ctx);
-/* raw device pointer of env.wave (12*nx*ny*3 floats) for zero-copy interop (RCCL, torch); valid until wv_destroy */
+/* raw device pointer of env.wave (12*nx*ny*3 floats) for zero-copy interop (RCCL, torch); valid until wv_destroy.
+ * The caller may WRITE through it between integrate calls: from this call until wv_release_device_frames every
+ * wv_integrate looks at the state afresh (the reduced-field-set precondition of the step kernels, the initial energies
+ * of the trace) instead of relying on what it left there itself. */
 int wv_device_frames(wv_ctx *ctx, void **dptr, size_t *bytes);
+int wv_release_device_frames(wv_ctx *ctx);
+/* Self-test of the one hardware property the resident step kernel relies on beyond the ISA's promises: a 16-byte-aligned
+ * 16-byte agent-scope buffer access (the {3 values, tag} granule of its halo exchange, csrc/fused_body.h) is never observed
+ * torn.  Writers on all XCDs rewrite self-describing granules for `iters` rounds while readers check them; returns the
+ * number of granules checked and the number found torn (expected: 0).  No reference counterpart. */
+int wv_selftest_granules(wv_ctx *ctx, int iters, unsigned long long *checked, unsigned long long *torn);
 /* raw device pointer of the source shape (nx*ny floats) */
 int wv_device_source_shape(wv_ctx *ctx, void **dptr, size_t *bytes);
 

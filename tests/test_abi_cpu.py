@@ -25,7 +25,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert len(syms) >= 30
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/waves_amd.h but not exported"
-    assert _ffi.lib().wv_abi_version() == 1
+    assert _ffi.lib().wv_abi_version() == 2
 
 
 def test_ffi_binds_every_declared_symbol():

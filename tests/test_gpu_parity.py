@@ -219,6 +219,7 @@ def test_env_rollout_matches_oracle_env(impl):
         assert np.array_equal(env.design.stacked().r, wo.stacked_cylinders(oenv.design).r)
     assert env.is_terminated() and oenv.signal[-1, 2] > 1e-6 * oenv.signal[-1, 0] > 0
     assert abs(env.reward() - oenv.reward()) <= ENERGY_RTOL * abs(oenv.reward())
+    env.ctx.close()
 
 
 @pytest.mark.parametrize("impl", IMPLS)

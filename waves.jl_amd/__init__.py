@@ -13,8 +13,8 @@ from .designs import (AIR, ALUMINIUM, BRASS, COPPER, WATER, AdjustablePositionSc
                       stack)
 from .dims import TwoDim, build_dirichlet, build_grid, build_wave, get_dx, get_dy
 from .dynamics import AcousticDynamics, Integrator, UniformSpeed, build_tspan, runge_kutta
-from .env import (FRAMESKIP, RandomDesignPolicy, WaveEnv, WaveEnvState, action_space, is_terminated, reset, reward, state,
-                  step_all)
+from .env import (FRAMESKIP, RandomDesignPolicy, WaveEnv, WaveEnvState, action_space, is_terminated, reset, reward,
+                  rollout_pipelined, state, step_all)
 from .sources import NoSource, RandomPosGaussianSource, Source
 
 __all__ = [n for n in dir() if not n.startswith("_")]

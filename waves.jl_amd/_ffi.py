@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -102,6 +103,8 @@ def lib():
     _sig(L, "wv_set_stream", [ctx, _vp])
     _sig(L, "wv_synchronize", [ctx])
     _sig(L, "wv_device_frames", [ctx, C.POINTER(_vp), C.POINTER(C.c_size_t)])
+    _sig(L, "wv_release_device_frames", [ctx])
+    _sig(L, "wv_selftest_granules", [ctx, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)])
     _sig(L, "wv_device_source_shape", [ctx, C.POINTER(_vp), C.POINTER(C.c_size_t)])
     _lib = L
     return L
@@ -163,7 +166,12 @@ class Context:
             self._h = None
 
     def __del__(self):
+        # At interpreter shutdown the HIP runtime (and a profiler's tool library) may already be finalising: freeing
+        # device memory from a destructor then runs inside exit handlers and has been seen to crash them.  Contexts that
+        # matter are closed explicitly; the driver reclaims the rest with the process.
         try:
+            if sys.is_finalizing():
+                return
             self.close()
         except Exception:
             pass
@@ -279,19 +287,29 @@ class Context:
         self._traj_stride = int(stride)
 
     def integrate_begin(self, tspan, *, capture_frames=False, want_signal=True, want_fields=False):
+        """Enqueue one integrate call and return.  A second call may be begun before the first is ended (the host then
+        prepares call k+1 while call k runs); integrate_end ends the oldest pending call."""
         ts = np.ascontiguousarray(tspan, np.float32).reshape(-1)
         n = len(ts) - 1
-        self._pend = (n, bool(want_signal), bool(want_fields))
         self._ck(self._L.wv_integrate_begin(self._h, fptr(ts), n, int(bool(capture_frames)), int(bool(want_signal)),
                                             int(bool(want_fields))))
+        if not hasattr(self, "_pend"):
+            self._pend = []
+        self._pend.append((n, bool(want_signal), bool(want_fields)))
+
+    def pending(self) -> int:
+        return len(getattr(self, "_pend", ()))
 
     def integrate_end(self):
-        n, ws, wf = self._pend
+        if not getattr(self, "_pend", None):  # nothing pending: let the library say so (WV_ERR_STATE)
+            self._ck(self._L.wv_integrate_end(self._h, None, None, None))
+        n, ws, wf = self._pend[0]
         sig = np.empty((n + 1, 3), np.float32) if ws else None
         planes = n // getattr(self, "_traj_stride", 1) + 1
         ut = np.empty((self.nx, self.ny, planes), np.float32, order="F") if wf else None
         ui = np.empty((self.nx, self.ny, planes), np.float32, order="F") if wf else None
         self._ck(self._L.wv_integrate_end(self._h, fptr(sig), fptr(ut), fptr(ui)))
+        self._pend.pop(0)
         return sig, ut, ui
 
     # --- measurement / plumbing
@@ -315,6 +333,16 @@ class Context:
         p, n = _vp(), C.c_size_t(0)
         self._ck(self._L.wv_device_frames(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def release_device_frames(self):
+        """The raw pointer of device_frames() is no longer written by the caller."""
+        self._ck(self._L.wv_release_device_frames(self._h))
+
+    def selftest_granules(self, iters=20000):
+        """(granules checked, granules found torn) of the 16-byte exchange-granule self-test."""
+        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+        self._ck(self._L.wv_selftest_granules(self._h, int(iters), C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def device_source_shape(self):
         p, n = _vp(), C.c_size_t(0)

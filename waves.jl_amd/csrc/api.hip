@@ -41,44 +41,50 @@ struct wv_ctx {
     std::vector<float> d0, d1;
     float ti = 0.0f, tf = 0.0f;
 
-    Cyl *d_cyl = nullptr;
+    Cyl *d_cyl = nullptr;      // one stage time: wv_speed_field / wv_rhs
     size_t cyl_cap = 0;
     std::vector<Cyl> h_cyl;
-    std::vector<float> h_sfac;
-    float *d_epart = nullptr;
-    size_t epart_cap = 0;
-    float *d_signal = nullptr;
-    float *h_signal = nullptr;   // pinned: the energy trace is copied here inside the call's stream work
-    size_t h_signal_cap = 0;
-    size_t signal_cap = 0;
     float *d_traj = nullptr;
     int traj_stride = 1;       // wv_set_trajectory_stride: every traj_stride-th saved time goes to u_tot / u_inc
-    int pend_planes = 0;       // planes per trajectory of the pending call
     size_t traj_cap = 0;
     float *d_small = nullptr;  // gaussian parameters
     size_t small_cap = 0;
     float *d_obs = nullptr;    // wv_observation output
     size_t obs_cap = 0;
-    float *d_sfac = nullptr;   // per-step source time factors [nsteps][3]
-    size_t sfac_cap = 0;
     std::vector<FusedStep> fsteps;
     bool counted = false;  // this ctx is included in g_live_ctx
-    bool bracketed = false;  // kev[0] / kev[1] bracket the fused launch(es) of the pending call
-    int prof_launches = 0, prof_events = 0;  // profiling mode: integrator launches / event pairs of the last call
-    float *d_elast = nullptr;  // per-block energy partials of the state the last integrate ended on
-    size_t elast_cap = 0;
     int elast_generation = -1;
-    bool elast_valid = false;  // ... still describing the current state (so row 1 of a step == last row of the previous)
+    bool elast_valid = false;  // elast still describes the current state (so row 1 of a step == last row of the previous)
+    const float *elast = nullptr;  // per-block energy partials of the state the last integrate ended on (inside a slot's d_epart)
+    int elast_blocks = 0;
+    bool frames_exposed = false;  // wv_device_frames handed the state out: the caller may write it at any time
+
+    // Up to two integrate calls are in flight (the host prepares call k+1 while call k runs on the device): everything a
+    // call's device work reads or writes that differs from call to call exists once per slot; calls alternate slots.
+    struct Slot {
+        Cyl *d_cyl = nullptr, *h_cyl = nullptr;      // [nsteps][3][M] cylinders at the stage times (device / pinned staging)
+        size_t cyl_cap = 0;
+        float *d_sfac = nullptr, *h_sfac = nullptr;  // [nsteps][3] source time factors
+        size_t sfac_cap = 0;
+        float *d_epart = nullptr;                    // [nsteps + 1][nblocks][3] energy partials
+        size_t epart_cap = 0;
+        float *h_signal = nullptr;                   // pinned: the device writes the energy trace straight into it
+        size_t signal_cap = 0;
+        hipEvent_t ev1 = nullptr;                    // after the last device work of the call
+        std::vector<hipEvent_t> kev;                 // kev[0] / kev[1] bracket the integrator launch(es); more when profiling
+        bool pending = false;
+        int nsteps = 0, planes = 0, impl = 0;
+        bool want_signal = false, want_fields = false, bracketed = false, resident = false;
+        int prof_launches = 0, prof_events = 0;
+    } slot[2];
+    int next_slot = 0;   // slot of the next wv_integrate_begin
+    int n_pending = 0;   // calls begun and not ended (the oldest is slot[(next_slot + 2 - n_pending) % 2])
+    hipStream_t up_stream = nullptr;  // uploads of the per-call tables, overlapped with the previous call's kernels
+    hipEvent_t up_ev = nullptr;
 
     FusedPlan *fused = nullptr;
 
-    bool pending = false;
-    int pend_nsteps = 0;
-    bool pend_signal = false, pend_fields = false;
-
     bool profiling = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::vector<hipEvent_t> kev;
     wv_timing timing{};
 
     std::string err;
@@ -192,6 +198,22 @@ static int ensure(wv_ctx *c, T **p, size_t *cap, size_t need)
     return WV_OK;
 }
 
+// device buffer + pinned staging buffer of `need` elements
+template <class T>
+static int ensure_pinned(wv_ctx *c, T **d, T **h, size_t *cap, size_t need)
+{
+    if (need <= *cap) return WV_OK;
+    if (*d) HIPCHK(c, hipFree(*d));
+    if (*h) HIPCHK(c, hipHostFree(*h));
+    *d = nullptr;
+    *h = nullptr;
+    *cap = 0;
+    HIPCHK(c, hipMalloc((void **)d, need * sizeof(T)));
+    HIPCHK(c, hipHostMalloc((void **)h, need * sizeof(T), hipHostMallocDefault));
+    *cap = need;
+    return WV_OK;
+}
+
 static float *frame(wv_ctx *c, int k) { return c->d_frames + (size_t)k * c->N; }
 
 // ---- ABI -------------------------------------------------------------------------------------------------
@@ -229,16 +251,24 @@ int wv_destroy(wv_ctx *c)
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     float *bufs[] = {c->d_x, c->d_y, c->d_sx, c->d_sy, c->d_frames, c->d_scratch[0], c->d_scratch[1], c->d_yA, c->d_yB,
-                     c->d_acc, c->d_G, c->d_plane[0], c->d_plane[1], c->d_epart, c->d_signal, c->d_traj, c->d_small, c->d_obs,
-                     c->d_elast, c->d_sfac};
+                     c->d_acc, c->d_G, c->d_plane[0], c->d_plane[1], c->d_traj, c->d_small, c->d_obs};
     for (float *b : bufs)
         if (b) (void)hipFree(b);
     if (c->d_cyl) (void)hipFree(c->d_cyl);
-    if (c->h_signal) (void)hipHostFree(c->h_signal);
+    if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
+    for (wv_ctx::Slot &q : c->slot) {
+        if (q.d_cyl) (void)hipFree(q.d_cyl);
+        if (q.h_cyl) (void)hipHostFree(q.h_cyl);
+        if (q.d_sfac) (void)hipFree(q.d_sfac);
+        if (q.h_sfac) (void)hipHostFree(q.h_sfac);
+        if (q.d_epart) (void)hipFree(q.d_epart);
+        if (q.h_signal) (void)hipHostFree(q.h_signal);
+        for (hipEvent_t e : q.kev) (void)hipEventDestroy(e);
+        if (q.ev1) (void)hipEventDestroy(q.ev1);
+    }
     if (c->fused) fused_destroy(c->fused);
-    for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->up_ev) (void)hipEventDestroy(c->up_ev);
+    if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return WV_OK;
@@ -296,8 +326,10 @@ int wv_create(const wv_config *cfg, const float *x, const float *y, wv_ctx **out
     CK(hipSetDevice(cfg->device));
     CK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
-    CK(hipEventCreate(&c->ev0));
-    CK(hipEventCreate(&c->ev1));
+    CK(hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+    CK(hipEventCreateWithFlags(&c->up_ev, hipEventDisableTiming));
+    CK(hipEventCreate(&c->slot[0].ev1));
+    CK(hipEventCreate(&c->slot[1].ev1));
     CK(hipMalloc((void **)&c->d_x, c->nx * sizeof(float)));
     CK(hipMalloc((void **)&c->d_y, c->ny * sizeof(float)));
     CK(hipMalloc((void **)&c->d_sx, c->nx * sizeof(float)));
@@ -357,7 +389,7 @@ int wv_set_pml(wv_ctx *c, const float *sigma_x, const float *sigma_y)
 {
     CHECK_CTX(c);
     if (!sigma_x || !sigma_y) return fail(c, WV_ERR_INVALID, "wv_set_pml: NULL profile");
-    if (c->pending) return fail(c, WV_ERR_STATE, "wv_set_pml: an integrate is pending");
+    if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_set_pml: an integrate is pending");
     c->sx.assign(sigma_x, sigma_x + c->nx);
     c->sy.assign(sigma_y, sigma_y + c->ny);
     HIPCHK(c, hipMemcpy(c->d_sx, c->sx.data(), c->nx * sizeof(float), hipMemcpyHostToDevice));
@@ -378,7 +410,7 @@ int wv_set_frames(wv_ctx *c, const float *wave)
 {
     CHECK_CTX(c);
     if (!wave) return fail(c, WV_ERR_INVALID, "wv_set_frames: NULL");
-    if (c->pending) return fail(c, WV_ERR_STATE, "wv_set_frames: an integrate is pending");
+    if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_set_frames: an integrate is pending");
     HIPCHK(c, hipMemcpyAsync(c->d_frames, wave, 3 * c->N * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     fused_state_changed(c->fused);
@@ -399,7 +431,7 @@ int wv_set_state(wv_ctx *c, const float *u)
 {
     CHECK_CTX(c);
     if (!u) return fail(c, WV_ERR_INVALID, "wv_set_state: NULL");
-    if (c->pending) return fail(c, WV_ERR_STATE, "wv_set_state: an integrate is pending");
+    if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_set_state: an integrate is pending");
     HIPCHK(c, hipMemcpyAsync(frame(c, 2), u, c->N * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     fused_state_changed(c->fused);
@@ -419,7 +451,7 @@ int wv_get_state(wv_ctx *c, float *u)
 int wv_reset(wv_ctx *c)
 {
     CHECK_CTX(c);
-    if (c->pending) return fail(c, WV_ERR_STATE, "wv_reset: an integrate is pending");
+    if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_reset: an integrate is pending");
     HIPCHK(c, hipMemsetAsync(c->d_frames, 0, 3 * c->N * sizeof(float), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     fused_state_zeroed(c->fused);
@@ -430,7 +462,7 @@ int wv_reset(wv_ctx *c)
 int wv_set_source_shape(wv_ctx *c, const float *shape, float freq)
 {
     CHECK_CTX(c);
-    if (c->pending) return fail(c, WV_ERR_STATE, "wv_set_source_shape: an integrate is pending");
+    if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_set_source_shape: an integrate is pending");
     c->has_source = shape != nullptr;
     c->freq = freq;
     if (shape) {
@@ -447,7 +479,7 @@ int wv_set_gaussian_source(wv_ctx *c, int K, const float *mu, const float *sigma
 {
     CHECK_CTX(c);
     if (K < 1 || !mu || !sigma || !a) return fail(c, WV_ERR_INVALID, "wv_set_gaussian_source: bad arguments");
-    if (c->pending) return fail(c, WV_ERR_STATE, "wv_set_gaussian_source: an integrate is pending");
+    if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_set_gaussian_source: an integrate is pending");
     int rc = ensure(c, &c->d_small, &c->small_cap, (size_t)4 * K);
     if (rc) return rc;
     std::vector<float> h(4 * (size_t)K);
@@ -479,7 +511,7 @@ int wv_observation(wv_ctx *c, int rx, int ry, float *out)
     if (!out) return fail(c, WV_ERR_INVALID, "wv_observation: NULL");
     if (rx < 1 || ry < 1 || rx > c->nx || ry > c->ny)
         return fail(c, WV_ERR_INVALID, "wv_observation: resolution must be within 1 .. grid size (src/env.jl:52)");
-    if (c->pending) return fail(c, WV_ERR_STATE, "wv_observation: an integrate is pending");
+    if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_observation: an integrate is pending");
     const size_t n = (size_t)rx * ry * 4;
     int rc = ensure(c, &c->d_obs, &c->obs_cap, n);
     if (rc) return rc;
@@ -497,8 +529,7 @@ int wv_set_design(wv_ctx *c, int M, const float *pos_i, const float *r_i, const 
     CHECK_CTX(c);
     if (M < 0 || M > 4096) return fail(c, WV_ERR_INVALID, "wv_set_design: M out of range [0, 4096]");
     if (M > 0 && (!pos_i || !r_i || !c_i || !pos_f || !r_f || !c_f)) return fail(c, WV_ERR_INVALID, "wv_set_design: NULL array");
-    if (c->pending) return fail(c, WV_ERR_STATE, "wv_set_design: an integrate is pending");
-    c->M = M;
+        c->M = M;
     c->ti = ti;
     c->tf = tf;
     c->d0.resize(4 * (size_t)M);
@@ -520,7 +551,7 @@ int wv_speed_field(wv_ctx *c, float t, float *out)
 {
     CHECK_CTX(c);
     if (!out) return fail(c, WV_ERR_INVALID, "wv_speed_field: NULL");
-    if (c->pending) return fail(c, WV_ERR_STATE, "wv_speed_field: an integrate is pending");
+    if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_speed_field: an integrate is pending");
     int rc = ensure(c, &c->d_cyl, &c->cyl_cap, (size_t)(c->M > 0 ? c->M : 1));
     if (rc) return rc;
     c->h_cyl.resize(c->M > 0 ? c->M : 1);
@@ -537,7 +568,7 @@ int wv_source_field(wv_ctx *c, float t, float *out)
 {
     CHECK_CTX(c);
     if (!out) return fail(c, WV_ERR_INVALID, "wv_source_field: NULL");
-    if (c->pending) return fail(c, WV_ERR_STATE, "wv_source_field: an integrate is pending");
+    if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_source_field: an integrate is pending");
     if (!c->has_source) {  // NoSource returns the scalar 0f0 (src/sources.jl:8)
         memset(out, 0, c->P * sizeof(float));
         return WV_OK;
@@ -553,7 +584,7 @@ int wv_gradient(wv_ctx *c, int axis, const float *u, float *out)
 {
     CHECK_CTX(c);
     if (!u || !out || (axis != 0 && axis != 1)) return fail(c, WV_ERR_INVALID, "wv_gradient: bad arguments");
-    if (c->pending) return fail(c, WV_ERR_STATE, "wv_gradient: an integrate is pending");
+    if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_gradient: an integrate is pending");
     HIPCHK(c, hipMemcpyAsync(c->d_plane[0], u, c->P * sizeof(float), hipMemcpyHostToDevice, c->stream));
     launch_gradient(c->grid, axis, c->d_plane[0], c->d_plane[1], c->stream);
     HIPCHK(c, hipGetLastError());
@@ -566,13 +597,14 @@ int wv_rhs(wv_ctx *c, const float *x, float t, float *k)
 {
     CHECK_CTX(c);
     if (!x || !k) return fail(c, WV_ERR_INVALID, "wv_rhs: NULL");
-    if (c->pending) return fail(c, WV_ERR_STATE, "wv_rhs: an integrate is pending");
+    if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_rhs: an integrate is pending");
     int rc = ensure(c, &c->d_cyl, &c->cyl_cap, (size_t)(c->M > 0 ? c->M : 1));
     if (rc) return rc;
     c->h_cyl.resize(c->M > 0 ? c->M : 1);
     design_at(c, t, c->h_cyl.data());
     if (c->M > 0) HIPCHK(c, hipMemcpy(c->d_cyl, c->h_cyl.data(), c->M * sizeof(Cyl), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpyAsync(c->d_scratch[0], x, c->N * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    fused_scratch_dirty(c->fused);  // the reduced field sets rely on zero auxiliary planes in the scratch states
     StageIO io{};
     io.yin = c->d_scratch[0];
     io.u = c->d_scratch[0];
@@ -626,9 +658,16 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     if (++g_hostprof.calls == 6) {  // the first calls allocate / load code: not representative
         for (double &a : g_hostprof.acc) a = 0.0;
         g_hostprof.calls = 1;
-        g_hostprof.on = g_hostprof.on;
     }
-    if (c->pending) return fail(c, WV_ERR_STATE, "wv_integrate_begin: previous integrate not ended");
+    // Two calls may be in flight: the second one is prepared (tables, culling, uploads on the copy stream) and enqueued
+    // while the first one runs; only the device state is sequentially dependent, and the stream orders that.
+    if (c->n_pending >= 2) return fail(c, WV_ERR_STATE, "wv_integrate_begin: two integrates are already pending");
+    if (c->n_pending == 1) {
+        const wv_ctx::Slot &o = c->slot[(c->next_slot + 1) % 2];
+        if (want_fields || o.want_fields || c->profiling)
+            return fail(c, WV_ERR_STATE, "wv_integrate_begin: previous integrate not ended (a second call may only be enqueued "
+                                         "when neither call returns trajectories and profiling is off)");
+    }
     if (!tspan || nsteps < 1) return fail(c, WV_ERR_INVALID, "wv_integrate: tspan NULL or nsteps < 1");
     if (capture && nsteps < 2 * WV_FRAMESKIP)
         return fail(c, WV_ERR_INVALID,
@@ -637,54 +676,66 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     const float dt = c->cfg.dt;
     const float hdt = 0.5f * dt;
     const int impl = c->cfg.impl == WV_IMPL_STAGED ? WV_IMPL_STAGED : WV_IMPL_FUSED;  // AUTO -> fused
+    const int si = c->next_slot;
+    wv_ctx::Slot &q = c->slot[si];
+    hipStream_t st = c->stream, up = c->up_stream;
 
-    // per-stage coefficient tables: stage times t, t + 0.5f0*dt, t + dt (src/dynamics.jl:10-13)
-    c->h_sfac.assign(3 * (size_t)nsteps, 0.0f);
-    c->h_cyl.resize(3 * (size_t)nsteps * (M > 0 ? M : 1));
+    // per-stage coefficient tables: stage times t, t + 0.5f0*dt, t + dt (src/dynamics.jl:10-13), built in pinned memory
+    // (the slot's buffers were last used by the call before the previous one, which has been ended)
+    const size_t ncyl = 3 * (size_t)nsteps * (M > 0 ? M : 1), nsf = 3 * (size_t)nsteps;
+    int rc = ensure_pinned(c, &q.d_cyl, &q.h_cyl, &q.cyl_cap, ncyl);
+    if (rc) return rc;
+    rc = ensure_pinned(c, &q.d_sfac, &q.h_sfac, &q.sfac_cap, nsf);
+    if (rc) return rc;
     int row_lo = 0, row_hi = 0;  // rows of the earliest / latest stage time (bounding boxes of the cylinder culling)
     float t_lo = INFINITY, t_hi = -INFINITY;
     bool t_ok = true;
     for (int s = 0; s < nsteps; ++s) {
         const float t = tspan[s];
         const float tq[3] = {t, t + hdt, t + dt};
-        for (int q = 0; q < 3; ++q) {
-            if (c->has_source) c->h_sfac[3 * s + q] = source_factor(tq[q], c->freq);
-            if (M > 0) design_at(c, tq[q], c->h_cyl.data() + (size_t)(3 * s + q) * M);
-            t_ok = t_ok && isfinite(tq[q]);
-            if (tq[q] < t_lo) { t_lo = tq[q]; row_lo = 3 * s + q; }
-            if (tq[q] > t_hi) { t_hi = tq[q]; row_hi = 3 * s + q; }
+        for (int k = 0; k < 3; ++k) {
+            q.h_sfac[3 * s + k] = c->has_source ? source_factor(tq[k], c->freq) : 0.0f;
+            if (M > 0) design_at(c, tq[k], q.h_cyl + (size_t)(3 * s + k) * M);
+            t_ok = t_ok && isfinite(tq[k]);
+            if (tq[k] < t_lo) { t_lo = tq[k]; row_lo = 3 * s + k; }
+            if (tq[k] > t_hi) { t_hi = tq[k]; row_hi = 3 * s + k; }
         }
     }
     if (!t_ok) row_lo = row_hi = -1;  // (a NaN time: let the culling look at every row)
     g_hostprof.lap(0);
-    int rc = ensure(c, &c->d_cyl, &c->cyl_cap, c->h_cyl.size());
-    if (rc) return rc;
-    if (M > 0)
-        HIPCHK(c, hipMemcpyAsync(c->d_cyl, c->h_cyl.data(), c->h_cyl.size() * sizeof(Cyl), hipMemcpyHostToDevice, c->stream));
-    rc = ensure(c, &c->d_sfac, &c->sfac_cap, c->h_sfac.size());
-    if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_sfac, c->h_sfac.data(), c->h_sfac.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-
+    if (M > 0) HIPCHK(c, hipMemcpyAsync(q.d_cyl, q.h_cyl, ncyl * sizeof(Cyl), hipMemcpyHostToDevice, up));
+    HIPCHK(c, hipMemcpyAsync(q.d_sfac, q.h_sfac, nsf * sizeof(float), hipMemcpyHostToDevice, up));
     g_hostprof.lap(1);
+    if (c->frames_exposed) {  // somebody holds the raw pointer of env.wave: assume it was written
+        fused_state_changed(c->fused);
+        c->elast_valid = false;
+    }
     if (impl == WV_IMPL_FUSED) {
         fused_allow_resident(c->fused, g_live_ctx[c->cfg.device & 63] <= 1);
-        rc = fused_prepare(c->fused, c->d_frames, c->d_scratch[0], c->d_scratch[1], capture != 0,
-                           c->has_source ? c->d_G : nullptr, c->d_cyl, M > 0 ? c->h_cyl.data() : nullptr, M, 3 * nsteps,
-                           c->stream, row_lo, row_hi);
+        rc = fused_prepare(c->fused, si, c->d_frames, c->d_scratch[0], c->d_scratch[1], capture != 0,
+                           c->has_source ? c->d_G : nullptr, q.d_cyl, M > 0 ? q.h_cyl : nullptr, M, 3 * nsteps, st, up, row_lo,
+                           row_hi);
         if (rc) return fail(c, rc == 2 ? WV_ERR_INVALID : WV_ERR_HIP, "fused_prepare failed");
         if (fused_generation(c->fused) != c->elast_generation) c->elast_valid = false;
         c->elast_generation = fused_generation(c->fused);
+    } else {
+        HIPCHK(c, hipEventRecord(c->up_ev, up));
+        HIPCHK(c, hipStreamWaitEvent(st, c->up_ev, 0));
     }
     g_hostprof.lap(2);
     const int nblocks = impl == WV_IMPL_STAGED ? staged_energy_blocks(c->grid) : fused_energy_blocks(c->fused);
     if (want_signal) {
-        rc = ensure(c, &c->d_epart, &c->epart_cap, (size_t)(nsteps + 1) * nblocks * 3);
+        rc = ensure(c, &q.d_epart, &q.epart_cap, (size_t)(nsteps + 1) * nblocks * 3);
         if (rc) return rc;
-        if ((size_t)nblocks * 3 > c->elast_cap) c->elast_valid = false;
-        rc = ensure(c, &c->d_elast, &c->elast_cap, (size_t)nblocks * 3);
-        if (rc) return rc;
-        rc = ensure(c, &c->d_signal, &c->signal_cap, (size_t)(nsteps + 1) * 3);
-        if (rc) return rc;
+        const size_t ns = (size_t)(nsteps + 1) * 3;
+        if (ns > q.signal_cap) {
+            if (q.h_signal) (void)hipHostFree(q.h_signal);
+            q.h_signal = nullptr;
+            q.signal_cap = 0;
+            HIPCHK(c, hipHostMalloc((void **)&q.h_signal, ns * sizeof(float), hipHostMallocDefault));
+            q.signal_cap = ns;
+        }
+        if (c->elast_blocks != nblocks) c->elast_valid = false;
     }
     const int tstride = c->traj_stride;
     const int nplanes = nsteps / tstride + 1;  // saved times 0, stride, 2*stride, ... <= nsteps
@@ -692,36 +743,38 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
         rc = ensure(c, &c->d_traj, &c->traj_cap, (size_t)2 * nplanes * c->P);
         if (rc) return rc;
     }
-    {  // one pair of events always (it brackets the fused launch(es) of the call), one pair per step when profiling
+    {  // one pair of events always (it brackets the integrator launch(es) of the call), one pair per step when profiling
         const size_t want = c->profiling ? 2 * (size_t)nsteps : 2;
-        while (c->kev.size() < want) {
+        while (q.kev.size() < want) {
             hipEvent_t ev;
             HIPCHK(c, hipEventCreate(&ev));
-            c->kev.push_back(ev);
+            q.kev.push_back(ev);
         }
     }
 
     g_hostprof.lap(3);
-    hipStream_t st = c->stream;
-    HIPCHK(c, hipEventRecord(c->ev0, st));
-
     float *tt = want_fields ? c->d_traj : nullptr;                               // u_tot planes
     float *ti_ = want_fields ? c->d_traj + (size_t)nplanes * c->P : nullptr;        // u_inc planes
 
     float *cur = frame(c, 2);
+    // energies of the initial state: the very partial sums the previous call ended on when the state is unchanged (the
+    // reference sums the same array in both places, src/env.jl:105-111), else a fresh reduction
+    const float *row0 = nullptr;
     if (want_signal) {
-        // energies of the initial state: the very partial sums the previous call ended on when the state is unchanged
-        // (the reference sums the same array in both places, src/env.jl:105-111), else a fresh reduction
-        if (c->elast_valid)
-            HIPCHK(c, hipMemcpyAsync(c->d_epart, c->d_elast, (size_t)nblocks * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
-        else
-            launch_energy_partial(c->grid, cur, c->d_epart, nblocks, st);
+        if (c->elast_valid) {
+            row0 = c->elast;
+        } else {
+            launch_energy_partial(c->grid, cur, q.d_epart, nblocks, st);
+            row0 = q.d_epart;
+        }
     }
     if (want_fields) launch_copy_planes(cur, c->P, tt, ti_, st);
     if (capture && nsteps == 2 * WV_FRAMESKIP)
         HIPCHK(c, hipMemcpyAsync(frame(c, 0), cur, c->N * sizeof(float), hipMemcpyDeviceToDevice, st));
 
-    const FusedCall fcall{c->has_source ? c->d_G : nullptr, c->has_source ? c->d_sfac : nullptr, dt};
+    const FusedCall fcall{c->has_source ? c->d_G : nullptr, c->has_source ? q.d_sfac : nullptr, dt};
+    const bool staged_prof = c->profiling && impl == WV_IMPL_STAGED;
+    if (impl == WV_IMPL_STAGED && !c->profiling) HIPCHK(c, hipEventRecord(q.kev[0], st));
     c->fsteps.clear();
     for (int s = 1; s <= nsteps; ++s) {
         float *out;
@@ -733,14 +786,14 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
             HIPCHK(c, hipMemcpyAsync(c->d_scratch[0], cur, c->N * sizeof(float), hipMemcpyDeviceToDevice, st));
             cur = c->d_scratch[0];
         }
-        const Cyl *cyl_s = c->d_cyl + (size_t)(3 * (s - 1)) * (M > 0 ? M : 0);
-        const float *sf = c->h_sfac.data() + 3 * (size_t)(s - 1);
-        float *ep = want_signal ? c->d_epart + (size_t)s * nblocks * 3 : nullptr;
+        const Cyl *cyl_s = q.d_cyl + (size_t)(3 * (s - 1)) * (M > 0 ? M : 0);
+        const float *sf = q.h_sfac + 3 * (size_t)(s - 1);
+        float *ep = want_signal ? q.d_epart + (size_t)s * nblocks * 3 : nullptr;
         const bool keep_t = s % tstride == 0;
         float *tts = (tt && keep_t) ? tt + (size_t)(s / tstride) * c->P : nullptr;
         float *tis = (ti_ && keep_t) ? ti_ + (size_t)(s / tstride) * c->P : nullptr;
         const float *G = c->has_source ? c->d_G : nullptr;
-        if (c->profiling && impl == WV_IMPL_STAGED) HIPCHK(c, hipEventRecord(c->kev[2 * (s - 1)], st));
+        if (staged_prof) HIPCHK(c, hipEventRecord(q.kev[2 * (s - 1)], st));
         if (impl == WV_IMPL_STAGED) {
             StageIO io{};
             io.u = cur;
@@ -771,136 +824,140 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
             fs.traj_inc = tis;
             c->fsteps.push_back(fs);  // launched together below
         }
-        if (c->profiling && impl == WV_IMPL_STAGED) HIPCHK(c, hipEventRecord(c->kev[2 * (s - 1) + 1], st));
+        if (staged_prof) HIPCHK(c, hipEventRecord(q.kev[2 * (s - 1) + 1], st));
         cur = out;
     }
     g_hostprof.lap(4);
-    c->prof_launches = nsteps * (impl == WV_IMPL_STAGED ? 4 : 1);
-    c->prof_events = nsteps;
-    bool resident = false;
-    c->bracketed = false;
-    if (impl == WV_IMPL_FUSED && !c->profiling) {
+    q.prof_launches = nsteps * (impl == WV_IMPL_STAGED ? 4 : 1);
+    q.prof_events = nsteps;
+    q.bracketed = false;
+    q.resident = false;
+    if (impl == WV_IMPL_STAGED && !c->profiling) {
+        HIPCHK(c, hipEventRecord(q.kev[1], st));  // (whole chain of stage kernels: total_ms of the call)
+    } else if (impl == WV_IMPL_FUSED && !c->profiling) {
         // the integrator launch(es) of the call between two events: for the resident path that is exactly the one kernel
-        HIPCHK(c, hipEventRecord(c->kev[0], st));
-        if (fused_run(c->fused, fcall, c->fsteps.data(), (int)c->fsteps.size(), st) != 0)
+        HIPCHK(c, hipEventRecord(q.kev[0], st));
+        if (fused_run(c->fused, si, fcall, c->fsteps.data(), (int)c->fsteps.size(), st) != 0)
             return fail(c, WV_ERR_HIP, std::string("fused_run failed: ") + hipGetErrorString(hipGetLastError()));
-        HIPCHK(c, hipEventRecord(c->kev[1], st));
-        c->bracketed = true;
-        if (fused_last_resident(c->fused)) c->prof_launches = 1;
+        HIPCHK(c, hipEventRecord(q.kev[1], st));
+        q.bracketed = true;
+        q.resident = fused_last_resident(c->fused);
+        if (q.resident) q.prof_launches = 1;
     } else if (impl == WV_IMPL_FUSED) {
         // profiling: the single resident launch bracketed by one pair of events, else every step by its own pair
-        // (the events recorded inside the loop above are re-recorded here in stream order)
-        HIPCHK(c, hipEventRecord(c->kev[0], st));
-        const int rr = fused_try_resident(c->fused, fcall, c->fsteps.data(), (int)c->fsteps.size(), st);
+        HIPCHK(c, hipEventRecord(q.kev[0], st));
+        const int rr = fused_try_resident(c->fused, si, fcall, c->fsteps.data(), (int)c->fsteps.size(), st);
         if (rr > 0) return fail(c, WV_ERR_HIP, std::string("fused_try_resident failed: ") + hipGetErrorString(hipGetLastError()));
         if (rr == 0) {
-            HIPCHK(c, hipEventRecord(c->kev[1], st));
-            c->prof_launches = 1;
-            c->prof_events = 1;
-            resident = true;
+            HIPCHK(c, hipEventRecord(q.kev[1], st));
+            q.prof_launches = 1;
+            q.prof_events = 1;
+            q.resident = true;
         } else {
             for (int s = 0; s < nsteps; ++s) {
-                HIPCHK(c, hipEventRecord(c->kev[2 * s], st));
-                fused_launch(c->fused, fcall, s, c->fsteps[s], st);
-                HIPCHK(c, hipEventRecord(c->kev[2 * s + 1], st));
+                HIPCHK(c, hipEventRecord(q.kev[2 * s], st));
+                fused_launch(c->fused, si, fcall, s, c->fsteps[s], st);
+                HIPCHK(c, hipEventRecord(q.kev[2 * s + 1], st));
             }
         }
     }
     g_hostprof.lap(5);
     HIPCHK(c, hipGetLastError());
+    const int *ab_src = (impl == WV_IMPL_FUSED && q.resident) ? fused_abort_src(c->fused) : nullptr;
+    int *ab_dst = impl == WV_IMPL_FUSED ? fused_abort_dst(c->fused, si) : nullptr;
     if (want_signal) {
-        launch_energy_final(c->d_epart, nsteps + 1, nblocks, c->dOmega, c->d_signal, st);
-        // the trace goes to pinned host memory as part of the call: wv_integrate_end then only waits for an event
-        // (polling it: the wake-up of a blocking wait costs more than the copy) and copies 1.2 KB host to host
-        const size_t ns = (size_t)(nsteps + 1) * 3;
-        if (ns > c->h_signal_cap) {
-            if (c->h_signal) (void)hipHostFree(c->h_signal);
-            c->h_signal = nullptr;
-            c->h_signal_cap = 0;
-            HIPCHK(c, hipHostMalloc((void **)&c->h_signal, ns * sizeof(float), hipHostMallocDefault));
-            c->h_signal_cap = ns;
-        }
-        HIPCHK(c, hipMemcpyAsync(c->h_signal, c->d_signal, ns * sizeof(float), hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipMemcpyAsync(c->d_elast, c->d_epart + (size_t)nsteps * nblocks * 3, (size_t)nblocks * 3 * sizeof(float),
-                                 hipMemcpyDeviceToDevice, st));
+        // second pass of the reductions, written straight into pinned host memory together with the resident kernel's
+        // give-up word: wv_integrate_end only waits for the call's last event and copies 1.2 KB host to host
+        launch_energy_final(row0, q.d_epart, nsteps + 1, nblocks, c->dOmega, q.h_signal, ab_src, ab_dst, st);
+        c->elast = q.d_epart + (size_t)nsteps * nblocks * 3;
+        c->elast_blocks = nblocks;
+    } else if (ab_src) {
+        HIPCHK(c, hipMemcpyAsync(ab_dst, ab_src, sizeof(int), hipMemcpyDeviceToHost, st));
     }
     c->elast_valid = want_signal != 0;
-    HIPCHK(c, hipEventRecord(c->ev1, st));
+    HIPCHK(c, hipEventRecord(q.ev1, st));
     HIPCHK(c, hipGetLastError());
 
-    c->pending = true;
-    c->pend_nsteps = nsteps;
-    c->pend_signal = want_signal != 0;
-    c->pend_fields = want_fields != 0;
-    c->pend_planes = nplanes;
-    c->timing = wv_timing{};
-    c->timing.steps = nsteps;
-    c->timing.impl = impl;
+    q.pending = true;
+    q.nsteps = nsteps;
+    q.want_signal = want_signal != 0;
+    q.want_fields = want_fields != 0;
+    q.planes = nplanes;
+    q.impl = impl;
+    c->n_pending++;
+    c->next_slot = (si + 1) % 2;
     g_hostprof.lap(6);
-    c->timing.resident = resident || (impl == WV_IMPL_FUSED && !c->profiling && fused_last_resident(c->fused)) ? 1 : 0;
     return WV_OK;
 }
 
 int wv_integrate_end(wv_ctx *c, float *signal, float *u_tot, float *u_inc)
 {
     CHECK_CTX(c);
-    if (!c->pending) return fail(c, WV_ERR_STATE, "wv_integrate_end: no integrate pending");
-    c->pending = false;
-    const int n = c->pend_nsteps;
-    if (signal && !c->pend_signal) return fail(c, WV_ERR_STATE, "wv_integrate_end: signal was not requested in _begin");
-    if ((u_tot || u_inc) && !c->pend_fields) return fail(c, WV_ERR_STATE, "wv_integrate_end: fields were not requested in _begin");
+    if (!c->n_pending) return fail(c, WV_ERR_STATE, "wv_integrate_end: no integrate pending");
+    const int si = (c->next_slot + 2 - c->n_pending) % 2;  // the oldest pending call
+    wv_ctx::Slot &q = c->slot[si];
+    // (argument errors leave the call pending: its device work and the buffers it uses stay protected)
+    if (signal && !q.want_signal) return fail(c, WV_ERR_STATE, "wv_integrate_end: signal was not requested in _begin");
+    if ((u_tot || u_inc) && !q.want_fields) return fail(c, WV_ERR_STATE, "wv_integrate_end: fields were not requested in _begin");
+    const int n = q.nsteps;
     hipStream_t st = c->stream;
-    const size_t tp = (size_t)c->pend_planes * c->P;
+    const size_t tp = (size_t)q.planes * c->P;
     if (u_tot) HIPCHK(c, hipMemcpyAsync(u_tot, c->d_traj, tp * sizeof(float), hipMemcpyDeviceToHost, st));
     if (u_inc) HIPCHK(c, hipMemcpyAsync(u_inc, c->d_traj + tp, tp * sizeof(float), hipMemcpyDeviceToHost, st));
     if (!u_tot && !u_inc) {
         // everything the caller gets is already on its way (or here): poll the call's last event for a while before
-        // falling back to a blocking wait
+        // falling back to a blocking wait (the wake-up of a blocking wait costs more than the rest of this function)
         static const bool spin = !(getenv("WAVES_AMD_SPIN") && atoi(getenv("WAVES_AMD_SPIN")) == 0);
         bool done = false;
         if (spin) {
             const auto t0 = std::chrono::steady_clock::now();
             for (;;) {
-                const hipError_t q = hipEventQuery(c->ev1);
-                if (q == hipSuccess) {
+                const hipError_t e = hipEventQuery(q.ev1);
+                if (e == hipSuccess) {
                     done = true;
                     break;
                 }
-                if (q != hipErrorNotReady) {
+                if (e != hipErrorNotReady) {
                     (void)hipGetLastError();
                     break;
                 }
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
             }
         }
-        if (!done) HIPCHK(c, hipStreamSynchronize(st));
+        if (!done) HIPCHK(c, hipEventSynchronize(q.ev1));
     } else {
         HIPCHK(c, hipStreamSynchronize(st));
     }
-    if (signal) memcpy(signal, c->h_signal, (size_t)(n + 1) * 3 * sizeof(float));
-    if (c->timing.impl == WV_IMPL_FUSED) fused_dump_stamps(c->fused, st);
+    q.pending = false;
+    c->n_pending--;
+    if (signal) memcpy(signal, q.h_signal, (size_t)(n + 1) * 3 * sizeof(float));
+    if (q.impl == WV_IMPL_FUSED && c->n_pending == 0) fused_dump_stamps(c->fused, st);
+    c->timing = wv_timing{};
+    c->timing.steps = n;
+    c->timing.impl = q.impl;
+    c->timing.resident = q.resident ? 1 : 0;
     float ms = 0.0f;
-    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    c->timing.total_ms = ms;
-    if (c->timing.impl == WV_IMPL_FUSED && fused_finish(c->fused, st) != 0)
+    HIPCHK(c, hipEventElapsedTime(&ms, q.kev[0], q.ev1));
+    c->timing.total_ms = ms;  // first integrator launch -> last device work of the call
+    if (q.impl == WV_IMPL_FUSED && fused_finish(c->fused, si, st) != 0)
         return fail(c, WV_ERR_HIP, "wv_integrate: the resident step kernel gave up waiting for a neighbouring tile "
                                    "(device shared with another process?); the state is invalid: wv_reset / wv_set_state.  "
                                    "This context uses the single-step kernels from now on");
-    if (c->bracketed) {
+    if (q.bracketed) {
         float k = 0.0f;
-        HIPCHK(c, hipEventElapsedTime(&k, c->kev[0], c->kev[1]));
+        HIPCHK(c, hipEventElapsedTime(&k, q.kev[0], q.kev[1]));
         c->timing.step_kernel_ms = k;
-        c->timing.step_kernel_launches = c->prof_launches;
+        c->timing.step_kernel_launches = q.prof_launches;
     }
     if (c->profiling) {
         double sum = 0.0;
-        for (int s = 0; s < c->prof_events; ++s) {
+        for (int s = 0; s < q.prof_events; ++s) {
             float k = 0.0f;
-            HIPCHK(c, hipEventElapsedTime(&k, c->kev[2 * s], c->kev[2 * s + 1]));
+            HIPCHK(c, hipEventElapsedTime(&k, q.kev[2 * s], q.kev[2 * s + 1]));
             sum += k;
         }
         c->timing.step_kernel_ms = sum;
-        c->timing.step_kernel_launches = c->prof_launches;
+        c->timing.step_kernel_launches = q.prof_launches;
     }
     return WV_OK;
 }
@@ -916,7 +973,7 @@ int wv_set_trajectory_stride(wv_ctx *c, int stride)
 {
     CHECK_CTX(c);
     if (stride < 1) return fail(c, WV_ERR_INVALID, "wv_set_trajectory_stride: stride must be >= 1");
-    if (c->pending) return fail(c, WV_ERR_STATE, "wv_set_trajectory_stride: an integrate is pending");
+    if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_set_trajectory_stride: an integrate is pending");
     c->traj_stride = stride;
     return WV_OK;
 }
@@ -939,7 +996,7 @@ int wv_get_timing(wv_ctx *c, wv_timing *out)
 int wv_set_stream(wv_ctx *c, void *hip_stream)
 {
     CHECK_CTX(c);
-    if (c->pending) return fail(c, WV_ERR_STATE, "wv_set_stream: an integrate is pending");
+    if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_set_stream: an integrate is pending");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return WV_OK;
@@ -958,8 +1015,52 @@ int wv_device_frames(wv_ctx *c, void **dptr, size_t *bytes)
     if (!dptr) return fail(c, WV_ERR_INVALID, "wv_device_frames: NULL");
     *dptr = c->d_frames;
     if (bytes) *bytes = 3 * c->N * sizeof(float);
-    fused_state_changed(c->fused);  // the caller may write through the pointer
+    // the caller may write through the pointer at any time from now on: until wv_release_device_frames every integrate
+    // looks at the state afresh (reduced-field-set precondition, initial energies)
+    c->frames_exposed = true;
+    fused_state_changed(c->fused);
     c->elast_valid = false;
+    return WV_OK;
+}
+
+int wv_release_device_frames(wv_ctx *c)
+{
+    CHECK_CTX(c);
+    if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_release_device_frames: an integrate is pending");
+    c->frames_exposed = false;
+    fused_state_changed(c->fused);  // (whatever was written before the release is looked at once more)
+    c->elast_valid = false;
+    return WV_OK;
+}
+
+int wv_selftest_granules(wv_ctx *c, int iters, unsigned long long *checked, unsigned long long *torn)
+{
+    CHECK_CTX(c);
+    if (iters < 1 || !checked || !torn) return fail(c, WV_ERR_INVALID, "wv_selftest_granules: bad arguments");
+    if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_selftest_granules: an integrate is pending");
+    const unsigned bytes = 32u << 20;
+    unsigned char *buf = nullptr;
+    unsigned long long *out = nullptr, h[2] = {0, 0};
+    HIPCHK(c, hipMalloc((void **)&buf, bytes));
+    if (hipMalloc((void **)&out, 2 * sizeof(unsigned long long)) != hipSuccess) {
+        (void)hipFree(buf);
+        return fail(c, WV_ERR_NOMEM, "wv_selftest_granules: out of device memory");
+    }
+    hipError_t e = hipMemsetAsync(out, 0, 2 * sizeof(unsigned long long), c->stream);
+    // dense granules, one granule per 64-byte line, one granule per row of this grid (the x-border pattern)
+    const unsigned strides[3] = {16u, 64u, (unsigned)c->nx * 16u};
+    for (int k = 0; k < 3 && e == hipSuccess; ++k) {
+        e = hipMemsetAsync(buf, 0, bytes, c->stream);
+        if (e == hipSuccess) launch_selftest_granules(buf, bytes, iters, 128, strides[k], out, c->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h, out, sizeof(h), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(buf);
+    (void)hipFree(out);
+    if (e != hipSuccess) return fail(c, WV_ERR_HIP, std::string("wv_selftest_granules: ") + hipGetErrorString(e));
+    *checked = h[0];
+    *torn = h[1];
     return WV_OK;
 }
 

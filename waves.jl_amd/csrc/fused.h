@@ -41,23 +41,32 @@ void fused_dump_stamps(FusedPlan *p, hipStream_t s);  // diagnostic, no-op unles
 // frames = env.wave (3 states, the last one is the initial condition), scratch0/1 the two ping-pong states.
 // G = device source shape or nullptr (NoSource).
 // row_lo / row_hi: rows of h_table with the earliest / latest stage time (see plan_build_cyl), or -1.
-int fused_prepare(FusedPlan *p, float *frames, float *scratch0, float *scratch1, bool capture, const float *G,
-                  const Cyl *d_table, const Cyl *h_table, int M, int rows, hipStream_t s, int row_lo = -1, int row_hi = -1);
+// slot (0 / 1): which of the two sets of per-call device tables this call uses -- two calls may be in flight (the host
+// prepares call k+1 while call k runs), so everything a call's kernels read that differs from call to call exists twice.
+// The tile / cylinder-index tables are uploaded on `up` (a copy stream); `s` then waits for everything enqueued on `up`
+// so far, so the caller's own uploads on `up` (enqueued before this call) are covered by the same wait.
+int fused_prepare(FusedPlan *p, int slot, float *frames, float *scratch0, float *scratch1, bool capture, const float *G,
+                  const Cyl *d_table, const Cyl *h_table, int M, int rows, hipStream_t s, hipStream_t up, int row_lo = -1,
+                  int row_hi = -1);
+void fused_scratch_dirty(FusedPlan *p);  // somebody else wrote into the scratch states (wv_rhs)
 void fused_source_changed(FusedPlan *p);  // the source shape was replaced
 // one step, eagerly, as a single launch over all tiles (profiling mode brackets these with events)
-void fused_launch(FusedPlan *p, const FusedCall &call, int step, const FusedStep &st, hipStream_t s);
+void fused_launch(FusedPlan *p, int slot, const FusedCall &call, int step, const FusedStep &st, hipStream_t s);
 // all steps of a call: one launch of the resident kernel when the tiles fit the device at once, else a cached hipGraph of
 // single-step kernel nodes (WAVES_AMD_FUSED_GRAPH=0: eager launches).  Returns 0 on success.
-int fused_run(FusedPlan *p, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s);
+int fused_run(FusedPlan *p, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s);
 // After the stream has been waited for: 0, or 1 when the resident kernel of the last fused_run abandoned the call (a tile
 // waited in vain for its neighbours -- the state is then invalid; the protocol has been reset).
-int fused_finish(FusedPlan *p, hipStream_t s);
+int fused_finish(FusedPlan *p, int slot, hipStream_t s);
+// device word the resident kernel sets when it gives up / pinned host word of this slot the caller has it copied to
+const int *fused_abort_src(const FusedPlan *p);
+int *fused_abort_dst(FusedPlan *p, int slot);
 bool fused_last_resident(const FusedPlan *p);  // the last fused_run took the single-launch path
 // All steps in one cooperative launch of k_steps_resident.  Returns 0 when launched, -1 when this call cannot take that
 // path (more tiles than the device holds at once, a single step, diagnostics ...; the caller then launches step by
 // step), 1 on a HIP error.  fused_run tries this first.
 void fused_allow_resident(FusedPlan *p, bool allow);  // per call: false keeps this call on the single-step kernels
-int fused_try_resident(FusedPlan *p, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s);
+int fused_try_resident(FusedPlan *p, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s);
 void fused_variant_counts(const FusedPlan *p, int out[4]);  // tiles per field set: NONE, PX, PY, ALL
 
 }  // namespace wv

@@ -39,8 +39,13 @@ int staged_energy_blocks(const Grid &g);
 
 // aux kernels
 void launch_energy_partial(const Grid &g, const float *state, float *epart, int nblocks, hipStream_t s);
-// signal[r][c] = float(sum_b epart[r][b][c]) * dOmega for r in [0, nrows)
-void launch_energy_final(const float *epart, int nrows, int nblocks, float dOmega, float *signal, hipStream_t s);
+// signal[r][c] = float(sum_b epart[r][b][c]) * dOmega for r in [0, nrows); row 0 is read from row0 (which may be
+// epart itself); signal may be pinned host memory; *flag_dst = *flag_src (both may be nullptr)
+void launch_energy_final(const float *row0, const float *epart, int nrows, int nblocks, float dOmega, float *signal,
+                         const int *flag_src, int *flag_dst, hipStream_t s);
+// 16-byte granule atomicity self-test (see k_selftest_granules); out[0] += granules checked, out[1] += torn ones
+void launch_selftest_granules(unsigned char *buf, unsigned bytes, int iters, int nwriters, unsigned stride,
+                              unsigned long long *out, hipStream_t s);
 void launch_speed_field(const Grid &g, const Cyl *cyl, int M, float *out, hipStream_t s);
 void launch_gaussian(const Grid &g, int K, const float *mu, const float *sigma, const float *a, float *out,
                      hipStream_t s);

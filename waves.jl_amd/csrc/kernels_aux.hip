@@ -39,11 +39,15 @@ __global__ __launch_bounds__(TPB) void k_energy_partial(const float *__restrict_
 
 // Deterministic second pass: one block per saved time point sums that point's per-block partials in double, in a
 // fixed order, rounds once to fp32 and applies `* dOmega` in fp32 (src/env.jl:108-111).
-__global__ __launch_bounds__(TPB) void k_energy_final(const float *__restrict__ epart, int nblocks, float dOmega,
-                                                      float *__restrict__ signal)
+// Row 0 (the initial state) may live elsewhere: the partial sums the previous call ended on.  The signal may be pinned
+// host memory (the trace then needs no copy of its own); block 0 also forwards the give-up word of the resident kernel.
+__global__ __launch_bounds__(TPB) void k_energy_final(const float *__restrict__ row0, const float *__restrict__ epart, int nblocks,
+                                                      float dOmega, float *__restrict__ signal, const int *__restrict__ flag_src,
+                                                      int *__restrict__ flag_dst)
 {
     const int r = blockIdx.x;
-    const float *p = epart + (size_t)r * nblocks * 3;
+    const float *p = r == 0 ? row0 : epart + (size_t)r * nblocks * 3;
+    if (r == 0 && threadIdx.x == 0 && flag_dst) *flag_dst = flag_src ? *flag_src : 0;
     double s[3] = {0.0, 0.0, 0.0};
     for (int b = threadIdx.x; b < nblocks; b += TPB) {
         s[0] += (double)p[b * 3 + 0];
@@ -162,14 +166,52 @@ int grid1d(size_t n) { size_t b = (n + TPB - 1) / TPB; return (int)(b > 2048 ? 2
 
 }  // namespace
 
+// Self-test of what the halo exchange of k_steps_resident relies on: a 16-byte-aligned, 16-byte agent-scope (sc1) buffer
+// access is never observed torn.  Writer blocks rewrite granules {x, f(x), ~x, x ^ K} in a tight loop, reader blocks on
+// every XCD load them and check that the four dwords belong to one x (tools/micro/tear16.hip is the long-running form).
+typedef unsigned int st_u4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_selftest_granules(unsigned char *buf, unsigned bytes, int iters, int nwriters,
+                                                           unsigned stride, unsigned long long *out /* checked, torn */)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(buf, 0, (int)bytes, 0x00020000);
+    const unsigned slot = (blockIdx.x % nwriters) * 256u + threadIdx.x;
+    const unsigned off = (unsigned)(((unsigned long long)slot * stride) % bytes) & ~15u;
+    if ((int)blockIdx.x < nwriters) {
+        for (int i = 1; i <= iters; ++i) {
+            const unsigned x = (unsigned)i * 977u + slot;
+            __builtin_amdgcn_raw_buffer_store_b128(st_u4{x, x * 2654435761u + 1u, ~x, x ^ 0x9e3779b9u}, rs, (int)off, 0, 16);
+            if ((i & 7) == 0) __builtin_amdgcn_s_waitcnt(0);
+        }
+    } else {
+        unsigned long long bad = 0, seen = 0;
+        for (int i = 0; i < iters; ++i) {
+            const st_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 16);
+            if (v.x == 0 && v.y == 0 && v.z == 0 && v.w == 0) continue;  // not written yet
+            ++seen;
+            if (!(v.y == v.x * 2654435761u + 1u && v.z == ~v.x && v.w == (v.x ^ 0x9e3779b9u))) ++bad;
+        }
+        atomicAdd(out, seen);
+        if (bad) atomicAdd(out + 1, bad);
+    }
+#endif
+}
+
+void launch_selftest_granules(unsigned char *buf, unsigned bytes, int iters, int nwriters, unsigned stride,
+                              unsigned long long *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_selftest_granules, dim3(nwriters * 4), dim3(256), 0, s, buf, bytes, iters, nwriters, stride, out);
+}
+
 void launch_energy_partial(const Grid &g, const float *state, float *epart, int nblocks, hipStream_t s)
 {
     hipLaunchKernelGGL(k_energy_partial, dim3(nblocks), dim3(TPB), 0, s, state, state + 6 * g.P, g.P, epart);
 }
 
-void launch_energy_final(const float *epart, int nrows, int nblocks, float dOmega, float *signal, hipStream_t s)
+void launch_energy_final(const float *row0, const float *epart, int nrows, int nblocks, float dOmega, float *signal,
+                         const int *flag_src, int *flag_dst, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_energy_final, dim3(nrows), dim3(TPB), 0, s, epart, nblocks, dOmega, signal);
+    hipLaunchKernelGGL(k_energy_final, dim3(nrows), dim3(TPB), 0, s, row0, epart, nblocks, dOmega, signal, flag_src, flag_dst);
 }
 
 void launch_speed_field(const Grid &g, const Cyl *cyl, int M, float *out, hipStream_t s)

@@ -426,18 +426,23 @@ struct FusedPlan {
     bool scratch_clean = true;    // the two scratch states have zero auxiliary planes outside the PML
     bool frames_clean = true;     // ... and so have frames 0 and 1 (frame 2 is the initial condition itself)
     std::vector<int> idx;
-    TileDesc *d_tiles = nullptr;
-    size_t tiles_cap = 0;
-    int *d_idx = nullptr;
-    size_t idx_cap = 0;
+    // per-call tables, one set per slot (two calls may be in flight): device copies and pinned staging
+    int cur = 0;                  // slot of the call being prepared / launched
+    TileDesc *d_tiles[2] = {nullptr, nullptr};
+    TileDesc *h_tiles[2] = {nullptr, nullptr};
+    size_t tiles_cap[2] = {0, 0};
+    int *d_idx[2] = {nullptr, nullptr};
+    int *h_idx[2] = {nullptr, nullptr};
+    size_t idx_cap[2] = {0, 0};
+    hipEvent_t up_ev[2] = {nullptr, nullptr};
     int *d_flag = nullptr;
     const Cyl *d_table = nullptr;
     int M = 0;
     int nbands = 1;               // tile bands per step in graph mode (WAVES_AMD_FUSED_BANDS)
     bool use_graph = true;        // WAVES_AMD_FUSED_GRAPH=0 disables
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    std::vector<char> graph_key;  // everything the cached graph's kernel arguments were built from
+    hipGraph_t graph[2] = {nullptr, nullptr};
+    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+    std::vector<char> graph_key[2];  // everything the cached graph's kernel arguments were built from
     unsigned long long *d_stamps = nullptr;  // diagnostic (WAVES_AMD_STAMPS=<file>)
     size_t stamps_cap = 0;
     const char *stamps_path = nullptr;
@@ -447,15 +452,15 @@ struct FusedPlan {
     int max_polls = WV_WAIT_POLLS;
     int resident_capacity = -1;   // blocks of k_steps_resident the device holds at once (-1: not asked yet)
     int cu_count = 0;
-    StepIO *d_steps = nullptr;
-    size_t steps_cap = 0;
-    std::vector<StepIO> h_steps;  // what d_steps holds
+    StepIO *d_steps[2] = {nullptr, nullptr};
+    size_t steps_cap[2] = {0, 0};
+    std::vector<StepIO> h_steps[2];  // what d_steps holds
     unsigned long long *d_xch = nullptr;  // tagged halo exchange buffer: [2 parities][4 planes][P] granules of 16 bytes, see fused_xch_*
     unsigned tag_base = 0;        // tags handed out so far (the buffer never holds a tag above it)
     unsigned tag_base_init = 0;   // diagnostic: first tag base after the buffer is created
     int *d_abort = nullptr;
-    int *h_abort = nullptr;       // pinned copy, valid after the stream has been waited for
-    bool abort_pending = false;   // a resident launch is in flight (or finished) whose verdict has not been looked at
+    int *h_abort = nullptr;       // pinned copies [2] (one per slot), valid after the call's last event
+    bool abort_pending[2] = {false, false};  // a resident launch is in flight (or finished) whose verdict has not been looked at
     bool last_resident = false;   // the last fused_run took the single-launch path
 };
 
@@ -486,29 +491,36 @@ FusedPlan *fused_create(const Grid &g, const float *x, const float *y, const flo
     if (const char *e = getenv("WAVES_AMD_FUSED_RESIDENT")) p->use_resident = atoi(e) != 0;
     if (const char *e = getenv("WAVES_AMD_TAG_BASE")) p->tag_base_init = (unsigned)strtoul(e, nullptr, 0);  // tests: wrap
     if (hipMalloc((void **)&p->d_flag, sizeof(int)) != hipSuccess || hipMalloc((void **)&p->d_abort, 4 * sizeof(int)) != hipSuccess ||
-        hipHostMalloc((void **)&p->h_abort, sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&p->h_abort, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&p->up_ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->up_ev[1], hipEventDisableTiming) != hipSuccess ||
         hipMemset(p->d_abort, 0, 4 * sizeof(int)) != hipSuccess) {
         fused_destroy(p);
         return nullptr;
     }
-    *p->h_abort = 0;
+    p->h_abort[0] = p->h_abort[1] = 0;
     return p;
 }
 
 void fused_destroy(FusedPlan *p)
 {
     if (!p) return;
-    if (p->d_tiles) (void)hipFree(p->d_tiles);
-    if (p->d_idx) (void)hipFree(p->d_idx);
+    for (int k = 0; k < 2; ++k) {
+        if (p->d_tiles[k]) (void)hipFree(p->d_tiles[k]);
+        if (p->h_tiles[k]) (void)hipHostFree(p->h_tiles[k]);
+        if (p->d_idx[k]) (void)hipFree(p->d_idx[k]);
+        if (p->h_idx[k]) (void)hipHostFree(p->h_idx[k]);
+        if (p->d_steps[k]) (void)hipFree(p->d_steps[k]);
+        if (p->up_ev[k]) (void)hipEventDestroy(p->up_ev[k]);
+        if (p->graph_exec[k]) (void)hipGraphExecDestroy(p->graph_exec[k]);
+        if (p->graph[k]) (void)hipGraphDestroy(p->graph[k]);
+    }
     if (p->d_flag) (void)hipFree(p->d_flag);
     if (p->d_stamps) (void)hipFree(p->d_stamps);
     if (p->d_src_flags) (void)hipFree(p->d_src_flags);
-    if (p->d_steps) (void)hipFree(p->d_steps);
     if (p->d_xch) (void)hipFree(p->d_xch);
     if (p->d_abort) (void)hipFree(p->d_abort);
     if (p->h_abort) (void)hipHostFree(p->h_abort);
-    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
-    if (p->graph) (void)hipGraphDestroy(p->graph);
     delete p;
 }
 
@@ -557,12 +569,32 @@ void fused_source_changed(FusedPlan *p) { p->src_dirty = true; }
 
 static int resident_capacity(FusedPlan *pl);
 
-int fused_prepare(FusedPlan *p, float *frames, float *scratch0, float *scratch1, bool capture, const float *G,
-                  const Cyl *d_table, const Cyl *h_table, int M, int rows, hipStream_t s, int row_lo, int row_hi)
+void fused_scratch_dirty(FusedPlan *p) { p->scratch_clean = false; }
+
+// device + pinned host buffer pair of `need` elements (grown generously: a new device pointer is a new kernel argument,
+// i.e. a re-instantiation of the cached hipGraph, ~40 ms)
+template <class T>
+static bool ensure_pair(T **d, T **h, size_t *cap, size_t need, size_t want)
+{
+    if (need <= *cap) return true;
+    if (*d) (void)hipFree(*d);
+    if (*h) (void)hipHostFree(*h);
+    *d = nullptr;
+    *h = nullptr;
+    *cap = 0;
+    if (hipMalloc((void **)d, want * sizeof(T)) != hipSuccess) return false;
+    if (hipHostMalloc((void **)h, want * sizeof(T), hipHostMallocDefault) != hipSuccess) return false;
+    *cap = want;
+    return true;
+}
+
+int fused_prepare(FusedPlan *p, int slot, float *frames, float *scratch0, float *scratch1, bool capture, const float *G,
+                  const Cyl *d_table, const Cyl *h_table, int M, int rows, hipStream_t s, hipStream_t up, int row_lo, int row_hi)
 {
     const Grid &g = p->g;
     const size_t N = g.P * kFields;
     float *ic = frames + 2 * N;
+    p->cur = slot;
     if (p->aux_state < 0) {  // the caller replaced the state: look at it once
         int h = 0;
         if (hipMemsetAsync(p->d_flag, 0, sizeof(int), s) != hipSuccess) return 1;
@@ -596,28 +628,18 @@ int fused_prepare(FusedPlan *p, float *frames, float *scratch0, float *scratch1,
     plan_build_cyl(p->hp, p->x.data(), p->y.data(), h_table, M, rows, p->idx, resort, (fits && pairing) ? p->cu_count : 0,
                    row_lo, row_hi);
     const size_t nt = p->hp.tiles.size();
-    if (nt > p->tiles_cap) {
-        if (p->d_tiles) (void)hipFree(p->d_tiles);
-        p->d_tiles = nullptr;
-        p->tiles_cap = 0;
-        if (hipMalloc((void **)&p->d_tiles, nt * sizeof(TileDesc)) != hipSuccess) return 1;
-        p->tiles_cap = nt;
-    }
     const size_t ni = p->idx.size() ? p->idx.size() : 1;
-    if (ni > p->idx_cap) {
-        // generous: the list grows and shrinks from call to call with the design, and a new device pointer is a new
-        // kernel argument, i.e. a re-instantiation of the cached hipGraph (~40 ms)
-        const size_t want = std::max(2 * ni, nt * 16);
-        if (p->d_idx) (void)hipFree(p->d_idx);
-        p->d_idx = nullptr;
-        p->idx_cap = 0;
-        if (hipMalloc((void **)&p->d_idx, want * sizeof(int)) != hipSuccess) return 1;
-        p->idx_cap = want;
-    }
-    if (hipMemcpyAsync(p->d_tiles, p->hp.tiles.data(), nt * sizeof(TileDesc), hipMemcpyHostToDevice, s) != hipSuccess) return 1;
+    // (the slot's buffers were last read by the call before the previous one, which the caller has ended)
+    if (!ensure_pair(&p->d_tiles[slot], &p->h_tiles[slot], &p->tiles_cap[slot], nt, nt)) return 1;
+    if (!ensure_pair(&p->d_idx[slot], &p->h_idx[slot], &p->idx_cap[slot], ni, std::max(2 * ni, nt * 16))) return 1;
+    memcpy(p->h_tiles[slot], p->hp.tiles.data(), nt * sizeof(TileDesc));
+    if (!p->idx.empty()) memcpy(p->h_idx[slot], p->idx.data(), p->idx.size() * sizeof(int));
+    if (hipMemcpyAsync(p->d_tiles[slot], p->h_tiles[slot], nt * sizeof(TileDesc), hipMemcpyHostToDevice, up) != hipSuccess) return 1;
     if (!p->idx.empty() &&
-        hipMemcpyAsync(p->d_idx, p->idx.data(), p->idx.size() * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess)
+        hipMemcpyAsync(p->d_idx[slot], p->h_idx[slot], p->idx.size() * sizeof(int), hipMemcpyHostToDevice, up) != hipSuccess)
         return 1;
+    // everything uploaded so far (the caller's coefficient tables included) before anything of this call runs on s
+    if (hipEventRecord(p->up_ev[slot], up) != hipSuccess || hipStreamWaitEvent(s, p->up_ev[slot], 0) != hipSuccess) return 1;
     if (G && p->src_dirty) {
         if (nt > p->src_flags_cap) {
             if (p->d_src_flags) (void)hipFree(p->d_src_flags);
@@ -626,11 +648,9 @@ int fused_prepare(FusedPlan *p, float *frames, float *scratch0, float *scratch1,
             if (hipMalloc((void **)&p->d_src_flags, nt) != hipSuccess) return 1;
             p->src_flags_cap = nt;
         }
-        hipLaunchKernelGGL(k_src_flags, dim3((unsigned)nt), dim3(256), 0, s, p->d_tiles, G, g.nx, g.ny, p->d_src_flags);
+        hipLaunchKernelGGL(k_src_flags, dim3((unsigned)nt), dim3(256), 0, s, p->d_tiles[slot], G, g.nx, g.ny, p->d_src_flags);
         p->src_dirty = false;
     }
-    // (the host vectors the copies above read are members of the plan and are next modified by the next prepare, i.e.
-    // after the caller has waited for this integrate call: no synchronisation needed here)
     p->d_table = d_table;
     p->M = M;
     return 0;
@@ -663,9 +683,9 @@ static FusedParams make_params(FusedPlan *pl, const FusedCall &call, int step, c
     p.M = pl->M;
     p.dt = call.dt;
     p.hdt = 0.5f * call.dt;
-    p.tiles = pl->d_tiles;
+    p.tiles = pl->d_tiles[pl->cur];
     p.tile_offset = 0;
-    p.cyl_idx = pl->d_idx;
+    p.cyl_idx = pl->d_idx[pl->cur];
     p.steps = nullptr;
     p.nsteps = 0;
     p.xch = nullptr;
@@ -695,8 +715,9 @@ static const void *kernel_ptr(const FusedPlan *pl)
     }
 }
 
-void fused_launch(FusedPlan *pl, const FusedCall &call, int step, const FusedStep &st, hipStream_t s)
+void fused_launch(FusedPlan *pl, int slot, const FusedCall &call, int step, const FusedStep &st, hipStream_t s)
 {
+    pl->cur = slot;
     FusedParams p = make_params(pl, call, step, st);
     void *args[1] = {&p};
     // WAVES_AMD_FUSED_PADLDS (diagnostic): extra dynamic LDS per block, to force one block per CU in occupancy studies
@@ -738,8 +759,9 @@ static int resident_capacity(FusedPlan *pl)
     return pl->resident_capacity;
 }
 
-int fused_try_resident(FusedPlan *pl, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s)
+int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s)
 {
+    pl->cur = slot;
     const size_t nt = pl->hp.tiles.size();
     if (nsteps < 2 || (int)nt > resident_capacity(pl)) return -1;
     // exchange buffer: zeroed once (tag 0 is never expected); tags only grow, so words of earlier calls -- or of an
@@ -762,25 +784,25 @@ int fused_try_resident(FusedPlan *pl, const FusedCall &call, const FusedStep *st
                         steps[i].traj_tot, steps[i].traj_inc, i, 0};
         if (i > 0 && steps[i].u != steps[i - 1].out) return -1;
     }
-    const bool same = tab.size() == pl->h_steps.size() &&
-                      memcmp(tab.data(), pl->h_steps.data(), tab.size() * sizeof(StepIO)) == 0;
+    const bool same = tab.size() == pl->h_steps[slot].size() &&
+                      memcmp(tab.data(), pl->h_steps[slot].data(), tab.size() * sizeof(StepIO)) == 0;
     if (!same) {
-        if (tab.size() > pl->steps_cap) {
-            if (pl->d_steps) (void)hipFree(pl->d_steps);
-            pl->d_steps = nullptr;
-            pl->steps_cap = 0;
-            pl->h_steps.clear();
-            if (hipMalloc((void **)&pl->d_steps, tab.size() * sizeof(StepIO)) != hipSuccess) return 1;
-            pl->steps_cap = tab.size();
+        if (tab.size() > pl->steps_cap[slot]) {
+            if (pl->d_steps[slot]) (void)hipFree(pl->d_steps[slot]);
+            pl->d_steps[slot] = nullptr;
+            pl->steps_cap[slot] = 0;
+            pl->h_steps[slot].clear();
+            if (hipMalloc((void **)&pl->d_steps[slot], tab.size() * sizeof(StepIO)) != hipSuccess) return 1;
+            pl->steps_cap[slot] = tab.size();
         }
-        // (a previous launch reading the old table on this stream is ordered before this copy; the host vector is not
-        // touched again until the next call, which the caller only makes after waiting for this one)
-        pl->h_steps = tab;
-        if (hipMemcpyAsync(pl->d_steps, pl->h_steps.data(), tab.size() * sizeof(StepIO), hipMemcpyHostToDevice, s) != hipSuccess)
+        // (rare: the table only changes with the call's shape.  The slot's previous launch has been ended by the caller;
+        // the host vector is not touched again before the slot's next call)
+        pl->h_steps[slot] = tab;
+        if (hipMemcpyAsync(pl->d_steps[slot], pl->h_steps[slot].data(), tab.size() * sizeof(StepIO), hipMemcpyHostToDevice, s) != hipSuccess)
             return 1;
     }
     FusedParams p = make_params(pl, call, 0, steps[0]);
-    p.steps = pl->d_steps;
+    p.steps = pl->d_steps[slot];
     p.nsteps = nsteps;
     p.xch = pl->d_xch;
     p.xch_bytes = (unsigned)(xwords * sizeof(unsigned long long));
@@ -797,40 +819,36 @@ int fused_try_resident(FusedPlan *pl, const FusedCall &call, const FusedStep *st
         return -1;
     }
     pl->tag_base += (unsigned)nsteps;
-    if (hipMemcpyAsync(pl->h_abort, pl->d_abort, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
-    pl->abort_pending = true;
+    pl->abort_pending[slot] = true;  // (the caller has the give-up word copied to fused_abort_dst(slot) behind the launch)
     return 0;
 }
 
-int fused_finish(FusedPlan *pl, hipStream_t s)
+const int *fused_abort_src(const FusedPlan *p) { return p->d_abort; }
+int *fused_abort_dst(FusedPlan *p, int slot) { return p->h_abort + slot; }
+
+int fused_finish(FusedPlan *pl, int slot, hipStream_t s)
 {
-#ifdef WV_XCH_VERIFY
-    {
-        int v[4] = {0, 0, 0, 0};
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpy(v, pl->d_abort, sizeof(v), hipMemcpyDeviceToHost);
-        fprintf(stderr, "[waves_amd verify] halo values that changed between two successful reads so far: %d\n", v[1]);
-    }
-#endif
-    if (!pl->abort_pending) return 0;
-    pl->abort_pending = false;
-    if (*pl->h_abort == 0) return 0;
+    if (!pl->abort_pending[slot]) return 0;
+    pl->abort_pending[slot] = false;
+    if (pl->h_abort[slot] == 0) return 0;
     // a tile gave up waiting: the state is garbage.  Reset the protocol so that the context stays usable, and keep this
     // context on the single-step kernels from now on: whatever kept a tile from running (another process's kernels on
-    // the same device, most likely) may well still be there at the next call.
-    *pl->h_abort = 0;
+    // the same device, most likely) may well still be there at the next call.  (A call already enqueued behind this one
+    // sees the word too and drains at once; its own verdict says so.)
+    pl->h_abort[slot] = 0;
     (void)hipMemsetAsync(pl->d_abort, 0, sizeof(int), s);
     pl->use_resident = false;
     return 1;
 }
 
-int fused_run(FusedPlan *pl, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s)
+int fused_run(FusedPlan *pl, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s)
 {
-    const int rr = fused_try_resident(pl, call, steps, nsteps, s);
+    const int rr = fused_try_resident(pl, slot, call, steps, nsteps, s);
+    pl->cur = slot;
     pl->last_resident = rr == 0;
     if (rr >= 0) return rr;
     if (!pl->use_graph || pl->stamps_path) {
-        for (int i = 0; i < nsteps; ++i) fused_launch(pl, call, i, steps[i], s);
+        for (int i = 0; i < nsteps; ++i) fused_launch(pl, slot, call, i, steps[i], s);
         return hipGetLastError() == hipSuccess ? 0 : 1;
     }
     // the graph's kernel arguments are functions of exactly these values: rebuild only when one of them changes
@@ -840,19 +858,19 @@ int fused_run(FusedPlan *pl, const FusedCall &call, const FusedStep *steps, int 
     key_put(key, call);
     key_put(key, pl->d_table);
     key_put(key, pl->M);
-    key_put(key, pl->d_tiles);
-    key_put(key, pl->d_idx);
+    key_put(key, pl->d_tiles[slot]);
+    key_put(key, pl->d_idx[slot]);
     key_put(key, pl->d_src_flags);
     key_put(key, pl->nbands);
     for (int i = 0; i < nsteps; ++i) key_put(key, steps[i]);
-    if (!pl->graph_exec || key != pl->graph_key) {
+    if (!pl->graph_exec[slot] || key != pl->graph_key[slot]) {
         if (getenv("WAVES_AMD_HOSTPROF")) fprintf(stderr, "[waves_amd] (re)building the step graph of plan %p\n", (void *)pl);
-        if (pl->graph_exec) (void)hipGraphExecDestroy(pl->graph_exec);
-        if (pl->graph) (void)hipGraphDestroy(pl->graph);
-        pl->graph_exec = nullptr;
-        pl->graph = nullptr;
-        pl->graph_key.clear();
-        if (hipGraphCreate(&pl->graph, 0) != hipSuccess) return 1;
+        if (pl->graph_exec[slot]) (void)hipGraphExecDestroy(pl->graph_exec[slot]);
+        if (pl->graph[slot]) (void)hipGraphDestroy(pl->graph[slot]);
+        pl->graph_exec[slot] = nullptr;
+        pl->graph[slot] = nullptr;
+        pl->graph_key[slot].clear();
+        if (hipGraphCreate(&pl->graph[slot], 0) != hipSuccess) return 1;
         const int B = (int)pl->hp.band_begin.size() - 1;
         std::vector<hipGraphNode_t> prev(B), cur(B);
         const void *fn = kernel_ptr(pl);
@@ -875,17 +893,17 @@ int fused_run(FusedPlan *pl, const FusedCall &call, const FusedStep *steps, int 
                 if (i > 0)
                     for (int d = b - 1; d <= b + 1; ++d)
                         if (d >= 0 && d < B) deps[nd++] = prev[d];
-                if (hipGraphAddKernelNode(&cur[b], pl->graph, nd ? deps : nullptr, nd, &kp) != hipSuccess) return 1;
+                if (hipGraphAddKernelNode(&cur[b], pl->graph[slot], nd ? deps : nullptr, nd, &kp) != hipSuccess) return 1;
             }
             prev = cur;
         }
-        if (hipGraphInstantiate(&pl->graph_exec, pl->graph, nullptr, nullptr, 0) != hipSuccess) {
-            pl->graph_exec = nullptr;
+        if (hipGraphInstantiate(&pl->graph_exec[slot], pl->graph[slot], nullptr, nullptr, 0) != hipSuccess) {
+            pl->graph_exec[slot] = nullptr;
             return 1;
         }
-        pl->graph_key = key;
+        pl->graph_key[slot] = key;
     }
-    return hipGraphLaunch(pl->graph_exec, s) == hipSuccess ? 0 : 1;
+    return hipGraphLaunch(pl->graph_exec[slot], s) == hipSuccess ? 0 : 1;
 }
 
 int fused_generation(const FusedPlan *p) { return p->generation; }

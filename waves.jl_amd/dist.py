@@ -29,7 +29,11 @@ def init(backend: str | None = None):
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
-        torch.cuda.set_device(local_rank)
+        n = torch.cuda.device_count()
+        if n == 0:
+            raise RuntimeError("waves_jl_amd.dist.init: backend nccl (RCCL) needs a GPU")
+        # (ranks that share a device -- rehearsals on a one-GPU box -- are the caller's decision: see bench.py)
+        torch.cuda.set_device(local_rank % n)
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")

@@ -85,7 +85,12 @@ class WaveEnv:
     def step_begin(self, action):
         """First half of env(action): enqueue the whole action on the env's HIP stream and return.  Several envs on one
         GPU overlap this way (`for e in envs: e.step_begin(a)` then `for e in envs: e.step_end()`): while one env's
-        tiles are in their load phase another's are computing (BASELINE config 3: 8 episodes per GPU)."""
+        tiles are in their load phase another's are computing (BASELINE config 3: 8 episodes per GPU).
+        One env may also have TWO actions in flight (step_begin, step_begin, step_end, step_begin, step_end, ...): the
+        host work of action k+1 (design algebra, coefficient tables, tile culling, uploads) then overlaps the device work
+        of action k; only the wave state is sequentially dependent and the stream orders that.  The bookkeeping that
+        does not depend on the device (env.design, env.time_step, src/env.jl:115,117) advances here; env.signal (:114)
+        in step_end."""
         tspan = self.build_tspan()
         ti = self.time()
         current_design = self.design
@@ -95,16 +100,17 @@ class WaveEnv:
             raise IndexError("BoundsError: sol[:, :, :, end-20:10:end] needs integration_steps >= 20 (src/env.jl:116)")
         self.ctx.set_design(*interp.abi_args())             # C = t -> speed(interp(t), grid, c0)
         self.ctx.integrate_begin(tspan, capture_frames=True, want_signal=True, want_fields=self.return_fields)
-        self._pending = (tspan, interp, next_design)
-
-    def step_end(self):
-        """Second half of env(action): wait for the device and update the env's bookkeeping (src/env.jl:114-120)."""
-        tspan, interp, next_design = self._pending
-        self._pending = None
-        sig, u_tot, u_inc = self.ctx.integrate_end()
-        self.signal = sig                                   # hcat(tot_energy, inc_energy, sc_energy)
+        if not hasattr(self, "_pending") or self._pending is None:
+            self._pending = []
+        self._pending.append((tspan, interp))
         self.design = next_design
         self.time_step += self.integration_steps
+
+    def step_end(self):
+        """Second half of env(action): wait for the device work of the oldest action in flight (src/env.jl:114,120)."""
+        tspan, interp = self._pending.pop(0)
+        sig, u_tot, u_inc = self.ctx.integrate_end()
+        self.signal = sig                                   # hcat(tot_energy, inc_energy, sc_energy)
         return tspan, interp, u_tot, u_inc
 
     def state(self):
@@ -122,6 +128,21 @@ class WaveEnv:
     def reward(self):
         """RLBase.reward  src/env.jl:147-149."""
         return np.sum(self.signal)
+
+
+def rollout_pipelined(env, policy, n_actions):
+    """`for _ in 1:n; env(policy(env)); end` with two actions in flight.  Valid for policies that do not look at the wave
+    state (RandomDesignPolicy, src/env.jl:151-157: it only samples its action space); returns the list of env.signal."""
+    sigs = []
+    for k in range(n_actions):
+        env.step_begin(policy(env))
+        if k > 0:
+            env.step_end()
+            sigs.append(env.signal)
+    if n_actions > 0:
+        env.step_end()
+        sigs.append(env.signal)
+    return sigs
 
 
 MAX_IN_FLIGHT = 4
