@@ -165,6 +165,42 @@ def make_env(w, dim, ds, dev, impl, pml_width, actions, seed, **kw):
     return env, policy
 
 
+class StubCtx:
+    """Stand-in for a device context (--stub-env): lets the rank logic of this script -- rendezvous, broadcast of the
+    design space, sharding, timed loop, gather, max over ranks, the JSON line -- run on a machine without a GPU."""
+
+    def timing(self):
+        return {"total_ms": 1.0, "step_kernel_ms": 0.9, "step_kernel_launches": 1, "steps": STEPS_PER_ACTION, "impl": "fused",
+                "resident": True}
+
+    def set_profiling(self, on):
+        pass
+
+    def close(self):
+        pass
+
+
+class StubEnv:
+    def __init__(self, seed):
+        self.ctx, self.rng, self.signal, self.n = StubCtx(), np.random.default_rng(seed), None, 0
+
+    def step_begin(self, action):
+        self.n += 1
+
+    def step_end(self):
+        self.signal = np.full((STEPS_PER_ACTION + 1, 3), float(self.n), np.float32)
+
+    def __call__(self, action):
+        self.step_begin(action)
+        self.step_end()
+
+
+def sync_device():
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
 def timed_rollout(env, policy, n_actions):
     """n_actions x env(policy(env)) with two actions in flight (w.rollout_pipelined spelled out to collect the timings)."""
     sigs, kern_ms, launches, dev_ms = [], 0.0, 0, 0.0
@@ -229,6 +265,7 @@ def main():
     ap.add_argument("--batch-envs", type=int, default=8,
                     help="extra (untimed-for-`value`) measurement at N=1: this many independent envs on the GPU (0 = skip)")
     ap.add_argument("--side-configs", type=int, default=1, help="N=1: also time 2048^2 and 256^2 after the headline (0 = skip)")
+    ap.add_argument("--stub-env", action="store_true", help=argparse.SUPPRESS)  # tests: rank logic without a GPU
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -264,13 +301,18 @@ def main():
     total_actions = args.warmup + args.steps
     envs, pols = [], []
     for e in range(E):
-        env, pol = make_env(w, dim, ds, dev, args.impl, args.pml_width, total_actions + 8, 1000 * rank + 17 * e)
+        if args.stub_env:
+            env, pol = StubEnv(1000 * rank + 17 * e), (lambda en: None)
+        else:
+            env, pol = make_env(w, dim, ds, dev, args.impl, args.pml_width, total_actions + 8, 1000 * rank + 17 * e)
         envs.append(env)
         pols.append(pol)
     env, policy = envs[0], pols[0]
 
     def sweep():
         return w.step_all(envs, [pol(en) for en, pol in zip(envs, pols)])
+
+    assert len(ds.low.config) == 18 and len(ds.low.core) == 1  # every rank holds rank 0's triple-ring block
 
     for _ in range(args.warmup):
         if E == 1:
@@ -286,7 +328,7 @@ def main():
     gc.freeze()
 
     wd.barrier()
-    torch.cuda.synchronize()
+    sync_device()
     t0 = time.perf_counter()
     dev_ms = 0.0
     kern_ms, kern_launches = 0.0, 0
@@ -303,8 +345,9 @@ def main():
                 kern_ms += t_["step_kernel_ms"]
                 kern_launches += t_["step_kernel_launches"]
     all_sig = wd.gather_signals(np.stack(sigs))
-    torch.cuda.synchronize()
+    sync_device()
     wd.barrier()
+    assert len(all_sig) == world
     elapsed = wd.max_over_ranks(time.perf_counter() - t0)
 
     cells = ngrid * ngrid
@@ -385,14 +428,15 @@ def main():
                          "whole_job_frac": round(B_ALG * value * 1e6 / world / (HBM_PEAK_GBS * 1e9), 4)},
             "signal_checksum": float(np.sum(all_sig[0][-1])),
         }
-        if world == 1 and args.side_configs and ngrid == N_GRID and E == 1:
+        out["ranks_gathered"] = len(all_sig)
+        if world == 1 and args.side_configs and ngrid == N_GRID and E == 1 and not args.stub_env:
             for en in envs:  # (a context takes the resident path only when it has the device to itself)
                 en.ctx.close()
             out["configs"] = {"config4_2048_w2": side_config(w, ds, dev, args.impl, 2048, 2.0, 3, traffic_tab),
                               "config1_size_256": side_config(w, ds, dev, args.impl, 256, 2.0, 10, traffic_tab)}
-        if world == 1 and args.batch_envs > 1 and E == 1:
+        if world == 1 and args.batch_envs > 1 and E == 1 and not args.stub_env:
             out["batched"] = batched_envs(w, dim, ds, dev, args.impl, args.batch_envs, args.pml_width)
-        if world == 1 and args.cpu_steps > 0:
+        if world == 1 and args.cpu_steps > 0 and not args.stub_env:
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
     for en in envs:   # explicit: nothing is left for destructors that would run while the process (or a profiler) shuts down
         en.ctx.close()

@@ -7,6 +7,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 import waves_jl_amd as w
 from waves_jl_amd import dist as wd
@@ -74,3 +75,39 @@ def test_two_gloo_ranks():
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {r} ok" in o
+
+
+def test_bench_rank_logic_two_ranks_self_spawned():
+    """`python bench.py --gpus 2` with no launcher: the script starts its two ranks itself (gloo here: no GPU), every rank
+    receives rank 0's design-space block, runs its two (stub) environments through the timed loop, the traces are gathered
+    and rank 0 prints ONE JSON line with the whole-job aggregate."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--cpu-steps", "0", "--stub-env", "--envs-per-gpu", "2"], capture_output=True, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["ranks_gathered"] == 2 and d["config"]["envs_per_gpu"] == 2 and d["scaling"] == "weak"
+    # 2 ranks x 2 envs x 2 actions x 100 steps x 700^2 cells over the (max-over-ranks) elapsed time
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 * 2 / (2 * 2 * 2 * 100 * 490000 / 1e6) - 1.0) < 1e-3
+
+
+def test_bench_without_gpu_fails_only_at_context_creation():
+    """Two real ranks on a machine without a GPU reach the rendezvous and the broadcast, then fail loudly where the device
+    is first needed: wv_create -> WV_ERR_NO_DEVICE (there is no CPU fallback)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--cpu-steps", "0"], capture_output=True, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
+    assert r.returncode != 0
+    assert "status 3" in r.stderr and "no CPU fallback" in r.stderr

@@ -4,10 +4,10 @@
 # Writes raw CSVs under gpurun_out/prof/ and a summary JSON (tools/pmc_summary.py) next to them.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$R/gpurun_out/prof
+OUT=$R/gpurun_out/${PROF_DIR:-prof}
 rm -rf "$OUT" && mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --cpu-steps 0 --batch-envs 0 $*"
+BENCH="python3 $R/bench.py --cpu-steps 0 --batch-envs 0 --side-configs 0 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- $BENCH --steps 5 --warmup 2 > "$OUT/kt.log" 2>&1
 echo "kernel-trace rc=$?"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc1" -o p -- $BENCH --steps 2 --warmup 1 > "$OUT/pmc1.log" 2>&1

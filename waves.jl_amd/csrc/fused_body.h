@@ -438,7 +438,11 @@ WV_HD void xch_put(const FusedParams &p, unsigned base, unsigned off, unsigned a
                  : "=&v"(o0), "=&v"(o1), "=&v"(o2)
                  : "v"(a), "v"(b), "v"(c));
     const wv_u4 w = {o0, o1, o2, tag};
+#ifdef WV_XCH_PLAINSTORE  // (timing experiment only: the stores stay in the XCD's L2)
+    __builtin_amdgcn_raw_buffer_store_b128(w, xch_rsrc(p), (int)off, (int)base, 0);
+#else
     __builtin_amdgcn_raw_buffer_store_b128(w, xch_rsrc(p), (int)off, (int)base, 16);  // aux 16: sc1
+#endif
 #else
     unsigned *q = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(p.xch) + base + off);
     q[0] = a;
@@ -665,6 +669,36 @@ WV_HD bool fused_xch_load(const FusedParams &p, unsigned tag, const TileDesc &t,
         }
     }
     return ok;
+}
+
+// Cheap look at the halo before the full read: ONE granule per lane (the incident-set granule of the lane's first halo
+// cell -- written after the total-set one).  A full read that comes too early costs every lane all its loads and the
+// register shuffling behind them a second time; spinning on this single load until it carries the tag costs next to
+// nothing.  Purely a timing device: fused_xch_load still checks every granule.
+template <int AUX, int NW, int RPT>
+WV_HD bool fused_xch_probe(const FusedParams &p, unsigned tag, const TileDesc &t, int tid)
+{
+    const int lane = tid & 63, w = tid >> 6;
+    const int gx = t.x0 - FT_H + lane;
+    const bool inx = gx >= 0 && gx < p.nx && lane < t.ox + 2 * FT_H;
+    const bool ownx = lane >= FT_H && lane < FT_H + t.ox;
+    bool have = false;
+    unsigned off = 0;
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) {
+        const int ly = w + NW * rr;
+        const int gy = t.y0 - FT_H + ly;
+        const bool in_row = gy >= 0 && gy < p.ny && ly < t.oy + 2 * FT_H;
+        const bool own = ownx && ly >= FT_H && ly < FT_H + t.oy;
+        const bool need = inx && in_row && !own;
+        if (need && !have) {
+            have = true;
+            off = ((unsigned)gy * (unsigned)p.nx + (unsigned)gx) * 16u;
+        }
+    }
+    unsigned tg = tag;
+    if (have) tg = xch_get(p, xch_plane_offset(p, tag & 1u, 1), xch_opaque(off)).t;
+    return tg == tag;
 }
 
 // phases 0a-0c of a single-step launch

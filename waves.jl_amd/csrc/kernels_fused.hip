@@ -268,8 +268,12 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
         const Cyl nc = fused_cyl_fetch<AUX, FL, RPT>(p, io.step + 1, t, tid, cx, r);
         bool ok = false;
         int polls = 0;
-#ifdef WV_POLL_DELAY  // (tuning experiment: the first poll is held back)
-        __builtin_amdgcn_s_sleep(WV_POLL_DELAY);
+#ifdef WV_XCH_PROBE  // (measured: the extra round trip in front of the full read costs 10 %)
+        // spin on one granule per lane first (bounded: the full poll below is what counts, and it watches the abort word)
+        for (int k = 0; k < 64; ++k) {
+            if (__all(fused_xch_probe<AUX, NW, RPT>(p, tag, t, tid))) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
 #endif
         for (; polls < p.max_polls; ++polls) {
             ok = __all(fused_xch_load<AUX, NW, RPT>(p, tag, t, tid, r));
