@@ -2,7 +2,7 @@
  *
  * Plain-C restatement of the WaveEnv integrator hot path of gladisor/Waves.jl,
  * written from the reference's source text.  Same arithmetic, operation order
- * and rounding as oracle/waves_oracle.py (tests/test_oracle_c.py checks the two
+ * and rounding as oracle/waves_oracle.py (tests/test_golden.py and tests/cpu_emu checks the two
  * bit-for-bit); it exists so that 700^2 / 2048^2 cases finish in seconds and as
  * the `cpu_baseline` ("port") leg of bench.py.
  *
