@@ -576,6 +576,7 @@ template <int AUX, int NW, int RPT>
 WV_HD bool fused_xch_load(const FusedParams &p, unsigned tag, const TileDesc &t, int tid, FusedRegs<AUX, RPT> &r)
 {
     constexpr int NS = aux_ns(AUX);
+    constexpr int NG = NS == 3 ? 2 : (AUX == AUX_ALL ? 4 : 3);  // granules a halo cell of this field set may need
     const int lane = tid & 63, w = tid >> 6;
     const int gx = t.x0 - FT_H + lane;
     const bool inx = gx >= 0 && gx < p.nx && lane < t.ox + 2 * FT_H;  // (columns beyond the region belong to nobody's ring)
@@ -584,6 +585,10 @@ WV_HD bool fused_xch_load(const FusedParams &p, unsigned tag, const TileDesc &t,
     const bool lx = r.sx != 0.0f;
     const unsigned PS = p.P * 16u;
     const unsigned base = xch_plane_offset(p, tag & 1u, 0);
+    // ---- first all the loads and the tag checks: a read that comes too early is abandoned here, before any of the
+    // register shuffling below (a failed attempt costs a wave ~40 instructions instead of ~140)
+    XchG g[RPT][NG];
+    int cls[RPT];
     bool ok = true;
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
@@ -591,66 +596,76 @@ WV_HD bool fused_xch_load(const FusedParams &p, unsigned tag, const TileDesc &t,
         const int gy = t.y0 - FT_H + ly;
         const bool in_row = gy >= 0 && gy < p.ny && ly < t.oy + 2 * FT_H;
         const int cgy = gy < 0 ? 0 : (gy >= p.ny ? p.ny - 1 : gy);
-        const bool rowown = ly >= FT_H && ly < FT_H + t.oy;
-        const bool own = ownx && rowown;
+        const bool own = ownx && ly >= FT_H && ly < FT_H + t.oy;
 #ifdef WV_XCH_NOLOAD  // (timing experiment only: no halo is read at all)
         const bool need = false && inx && in_row;
 #else
         const bool need = inx && in_row && !own;
 #endif
-        const unsigned row = (unsigned)cgy * (unsigned)p.nx;
-        const unsigned off = (row + (unsigned)cgx) * 16u;
-        XchG g0{0u, 0u, 0u, tag}, g1{0u, 0u, 0u, tag};
+        const unsigned off = ((unsigned)cgy * (unsigned)p.nx + (unsigned)cgx) * 16u;
+#pragma unroll
+        for (int k = 0; k < NG; ++k) g[rr][k] = XchG{0u, 0u, 0u, tag};
+        // With reduced field sets the owner of a halo cell carries -- and sends -- an auxiliary field only where that
+        // field can be non-zero (class of the cell); anywhere else its value is the exact zero the field-set invariant
+        // guarantees.  AUX_PX / AUX_PY tiles only exist with reduced field sets, and their region has sigma == 0 along the
+        // other axis: their one auxiliary field arrives in a class 1 / class 2 granule.
+        cls[rr] = 0;
+        if (AUX == AUX_PX) cls[rr] = lx ? 1 : 0;
+        if (AUX == AUX_PY) cls[rr] = p.sy[cgy] != 0.0f ? 2 : 0;
+        if (AUX == AUX_ALL) cls[rr] = xch_class(p, lx, p.sy[cgy] != 0.0f);
         if (need) {
             const unsigned o = xch_opaque(off);
-            g0 = xch_get(p, base, o);
-            g1 = xch_get(p, base + PS, o);
+            g[rr][0] = xch_get(p, base, o);
+            g[rr][1] = xch_get(p, base + PS, o);
+            if (NG > 2 && cls[rr] != 0) g[rr][2] = xch_get(p, base + 2 * PS, o);
+            if (NG > 3 && cls[rr] == 3) g[rr][3] = xch_get(p, base + 3 * PS, o);
         }
 #ifndef WV_XCH_NOWAIT  // (timing experiment only: results are wrong without the check)
-        ok = ok && g0.t == tag && g1.t == tag;
+#pragma unroll
+        for (int k = 0; k < NG; ++k) ok = ok && g[rr][k].t == tag;
+#endif
+#ifdef WV_XCH_DEBUG
+        if (need && !(g[rr][0].t == tag && g[rr][1].t == tag) && wv_xch_debug)
+            printf("  slot %d aux %d x0 %d y0 %d ox %d oy %d: lane %d ly %d gx %d gy %d has tags %u %u want %u\n", t.slot, t.aux, t.x0, t.y0, t.ox, t.oy, lane, ly, gx, gy, g[rr][0].t, g[rr][1].t, tag), wv_xch_debug--;
+#endif
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (!__all(ok)) return false;   // wave-uniform: the caller polls again
+#else
+    if (!ok) return false;
+#endif
+    // ---- then the new state of the step
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) {
+        const int ly = w + NW * rr;
+        const int gy = t.y0 - FT_H + ly;
+        const bool in_row = gy >= 0 && gy < p.ny && ly < t.oy + 2 * FT_H;
+        const bool own = ownx && ly >= FT_H && ly < FT_H + t.oy;
+#ifdef WV_XCH_NOLOAD
+        const bool need = false && inx && in_row;
+#else
+        const bool need = inx && in_row && !own;
 #endif
         float at[3] = {0.0f, 0.0f, 0.0f}, ai[3] = {0.0f, 0.0f, 0.0f};  // Psi_x, Psi_y, Omega of the halo cell
-        if (AUX == AUX_PX || AUX == AUX_PY) {
-            // one auxiliary field (these tiles only exist with reduced field sets, and their region has sigma == 0 along
-            // the other axis): the halo cell sends it -- in a class 1 / class 2 granule -- where it can be non-zero
-            const bool live = AUX == AUX_PX ? lx : p.sy[cgy] != 0.0f;
-            XchG h2{0u, 0u, 0u, tag};
-            if (need && live) h2 = xch_get(p, base + 2 * PS, xch_opaque(off));
-#ifndef WV_XCH_NOWAIT
-            ok = ok && h2.t == tag;
-#endif
-            at[AUX == AUX_PX ? 0 : 1] = __builtin_bit_cast(float, xch_copy(h2.a));
-            ai[AUX == AUX_PX ? 0 : 1] = __builtin_bit_cast(float, xch_copy(h2.b));
-        } else if (AUX == AUX_ALL) {
-            // With reduced field sets the owner of a halo cell carries -- and sends -- an auxiliary field only where that
-            // field can be non-zero; anywhere else its value is the exact zero the field-set invariant guarantees.
-            const int cls = xch_class(p, lx, p.sy[cgy] != 0.0f);
-            XchG h2{0u, 0u, 0u, tag}, h3{0u, 0u, 0u, tag};
-            if (need && cls != 0) {
-                const unsigned o = xch_opaque(off);
-                h2 = xch_get(p, base + 2 * PS, o);
-                if (cls == 3) h3 = xch_get(p, base + 3 * PS, o);
-            }
-#ifndef WV_XCH_NOWAIT
-            ok = ok && h2.t == tag && h3.t == tag;
-#endif
+        if (NG == 3) {
+            at[AUX == AUX_PX ? 0 : 1] = __builtin_bit_cast(float, xch_copy(g[rr][2].a));
+            ai[AUX == AUX_PX ? 0 : 1] = __builtin_bit_cast(float, xch_copy(g[rr][2].b));
+        } else if (NG == 4) {
             // (selects, not run-time indices: everything stays in registers)
+            const int c = cls[rr];
+            const XchG &h2 = g[rr][2], &h3 = g[rr][NG - 1];
             const float a2 = __builtin_bit_cast(float, xch_copy(h2.a)), b2 = __builtin_bit_cast(float, xch_copy(h2.b));
             const float c2 = __builtin_bit_cast(float, xch_copy(h2.c));
             const float a3 = __builtin_bit_cast(float, xch_copy(h3.a)), b3 = __builtin_bit_cast(float, xch_copy(h3.b));
             const float c3 = __builtin_bit_cast(float, xch_copy(h3.c));
-            at[0] = (cls & 1) ? a2 : 0.0f;
-            ai[0] = cls == 3 ? a3 : (cls == 1 ? b2 : 0.0f);
-            at[1] = cls == 3 ? b2 : (cls == 2 ? a2 : 0.0f);
-            ai[1] = cls == 3 ? b3 : (cls == 2 ? b2 : 0.0f);
-            at[2] = cls == 3 ? c2 : 0.0f;
-            ai[2] = cls == 3 ? c3 : 0.0f;
+            at[0] = (c & 1) ? a2 : 0.0f;
+            ai[0] = c == 3 ? a3 : (c == 1 ? b2 : 0.0f);
+            at[1] = c == 3 ? b2 : (c == 2 ? a2 : 0.0f);
+            ai[1] = c == 3 ? b3 : (c == 2 ? b2 : 0.0f);
+            at[2] = c == 3 ? c2 : 0.0f;
+            ai[2] = c == 3 ? c3 : 0.0f;
         }
-#ifdef WV_XCH_DEBUG
-        if (need && !(g0.t == tag && g1.t == tag) && wv_xch_debug)
-            printf("  slot %d aux %d x0 %d y0 %d ox %d oy %d: lane %d ly %d gx %d gy %d has tags %u %u want %u\n", t.slot, t.aux, t.x0, t.y0, t.ox, t.oy, lane, ly, gx, gy, g0.t, g1.t, tag), wv_xch_debug--;
-#endif
-        const unsigned v0[3] = {g0.a, g0.b, g0.c}, v1[3] = {g1.a, g1.b, g1.c};
+        const unsigned v0[3] = {g[rr][0].a, g[rr][0].b, g[rr][0].c}, v1[3] = {g[rr][1].a, g[rr][1].b, g[rr][1].c};
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             float vt = own ? r.y[rr][0][j] : 0.0f, vi = own ? r.y[rr][1][j] : 0.0f;
@@ -668,7 +683,7 @@ WV_HD bool fused_xch_load(const FusedParams &p, unsigned tag, const TileDesc &t,
             r.u[rr][1][j] = vi;
         }
     }
-    return ok;
+    return true;
 }
 
 // Cheap look at the halo before the full read: ONE granule per lane (the incident-set granule of the lane's first halo
