@@ -168,6 +168,14 @@ int wv_set_trajectory_stride(wv_ctx *ctx, int stride);
 int wv_integrate_begin(wv_ctx *ctx, const float *tspan, int nsteps, int capture_frames, int want_signal,
                        int want_fields);
 int wv_integrate_end(wv_ctx *ctx, float *signal, float *u_tot, float *u_inc);
+/* Trajectory streaming (render! / build_interpolator, src/plot.jl:24-45, need u_tot / u_inc of src/env.jl:120 on the
+ * host): with want_fields == 2 in _begin the planes of a call are copied to pinned host memory on a copy stream as soon
+ * as its kernels have finished -- i.e. while the NEXT call (begun before this one is ended) computes -- instead of being
+ * fetched by a blocking copy inside _end (want_fields == 1).  wv_integrate_end_view ends the oldest pending call and returns pointers to the planes
+ * ((nsteps / stride + 1) planes of nx*ny each, see wv_set_trajectory_stride) in library-owned pinned memory: valid until
+ * the second wv_integrate_begin after this call.  wv_integrate_end with u_tot / u_inc also works (one more host copy).
+ * Two streamed calls may be in flight. */
+int wv_integrate_end_view(wv_ctx *ctx, float *signal, const float **u_tot, const float **u_inc, int *planes);
 
 /* measurement and plumbing */
 int wv_set_profiling(wv_ctx *ctx, int on); /* bracket every step kernel with HIP events (slower; for roofline) */

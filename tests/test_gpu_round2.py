@@ -240,3 +240,64 @@ def test_state_written_through_the_raw_device_pointer_is_looked_at_again():
     assert rel_err(sig[:, :2], rsig[:, :2]) < ENERGY_RTOL
     ctx.release_device_frames()
     ctx.close()
+
+
+@pytest.mark.parametrize("n,stride,resident", [(300, 1, True), (700, 10, True), (300, 7, False)])
+def test_streamed_trajectories_equal_the_copied_ones(monkeypatch, n, stride, resident):
+    """want_fields = "stream": the saved u_tot / u_inc planes of an action go to pinned host memory on a copy stream
+    while the next action computes.  Same bits as the device-buffer-then-copy path; two streamed actions in
+    flight; views stay valid while the next action runs."""
+    gc.collect()
+    monkeypatch.setenv("WAVES_AMD_FUSED_RESIDENT", "1" if resident else "0")
+    steps = 40
+
+    def run(mode, pipelined):
+        env, pol = _env(n, steps, 3, 5, trajectory_stride=stride)
+        env.return_fields = mode
+        outs = []
+        if pipelined:
+            env.step_begin(pol(env))
+            env.step_begin(pol(env))
+            outs.append(env.step_end())
+            env.step_begin(pol(env))
+            first = (outs[0][2].copy(), outs[0][3].copy())
+            outs.append(env.step_end())
+            outs.append(env.step_end())
+            assert np.array_equal(outs[0][2], first[0]) and np.array_equal(outs[0][3], first[1])   # view survived one more begin
+        else:
+            for _ in range(3):
+                outs.append(env(pol(env)))
+        res = [(np.array(o[2]), np.array(o[3])) for o in outs]
+        assert env.ctx.timing()["resident"] is resident
+        env.ctx.close()
+        gc.collect()
+        return res
+
+    ref = run(True, False)
+    assert ref[0][0].shape == (n, n, steps // stride + 1)
+    got = run("stream", False)
+    got2 = run("stream", True)
+    for a, b, c in zip(ref, got, got2):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+
+
+def test_streamed_planes_are_transferred_under_the_next_action():
+    """700^2 actions that stream every 10th saved plane (11 x 2 planes = 43 MB per action) against actions that return no
+    fields, both as pipelined rollouts: the device-to-host copy of action k runs on its own stream while action k+1
+    computes.  Measured on the box of the round (tools/stream_cost.py, profiles/r02/stream_cost.txt): +8 % at stride 10
+    (the blocking copy of wv_integrate_end: +410 %); from stride 5 on the PCIe link (~50 GB/s) is the bound."""
+    import time
+    gc.collect()
+    times = {}
+    for mode in (False, "stream"):
+        env, pol = _env(700, 100, 30, 9, trajectory_stride=10)
+        env.return_fields = mode
+        for _ in range(3):
+            env(pol(env))
+        t0 = time.perf_counter()
+        w.rollout_pipelined(env, pol, 12)
+        times[mode] = time.perf_counter() - t0
+        env.ctx.close()
+        gc.collect()
+    assert times["stream"] < 1.2 * times[False], times

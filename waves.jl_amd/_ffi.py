@@ -97,6 +97,7 @@ def lib():
     _sig(L, "wv_integrate", [ctx, _fp, C.c_int, C.c_int, _fp, _fp, _fp])
     _sig(L, "wv_integrate_begin", [ctx, _fp, C.c_int, C.c_int, C.c_int, C.c_int])
     _sig(L, "wv_integrate_end", [ctx, _fp, _fp, _fp])
+    _sig(L, "wv_integrate_end_view", [ctx, _fp, C.POINTER(_fp), C.POINTER(_fp), C.POINTER(C.c_int)])
     _sig(L, "wv_set_trajectory_stride", [ctx, C.c_int])
     _sig(L, "wv_set_profiling", [ctx, C.c_int])
     _sig(L, "wv_get_timing", [ctx, C.POINTER(wv_timing)])
@@ -291,11 +292,11 @@ class Context:
         prepares call k+1 while call k runs); integrate_end ends the oldest pending call."""
         ts = np.ascontiguousarray(tspan, np.float32).reshape(-1)
         n = len(ts) - 1
-        self._ck(self._L.wv_integrate_begin(self._h, fptr(ts), n, int(bool(capture_frames)), int(bool(want_signal)),
-                                            int(bool(want_fields))))
+        wf = 2 if want_fields == "stream" else int(bool(want_fields))   # "stream": planes go to pinned host memory as they are produced
+        self._ck(self._L.wv_integrate_begin(self._h, fptr(ts), n, int(bool(capture_frames)), int(bool(want_signal)), wf))
         if not hasattr(self, "_pend"):
             self._pend = []
-        self._pend.append((n, bool(want_signal), bool(want_fields)))
+        self._pend.append((n, bool(want_signal), want_fields if want_fields == "stream" else bool(want_fields)))
 
     def pending(self) -> int:
         return len(getattr(self, "_pend", ()))
@@ -305,6 +306,14 @@ class Context:
             self._ck(self._L.wv_integrate_end(self._h, None, None, None))
         n, ws, wf = self._pend[0]
         sig = np.empty((n + 1, 3), np.float32) if ws else None
+        if wf == "stream":   # zero-copy views of the library's pinned planes (valid until the second integrate_begin from now)
+            pt, pi, npl = _fp(), _fp(), C.c_int(0)
+            self._ck(self._L.wv_integrate_end_view(self._h, fptr(sig), C.byref(pt), C.byref(pi), C.byref(npl)))
+            self._pend.pop(0)
+            shape = (npl.value, self.ny, self.nx)
+            ut = np.ctypeslib.as_array(pt, shape).transpose(2, 1, 0)
+            ui = np.ctypeslib.as_array(pi, shape).transpose(2, 1, 0)
+            return sig, ut, ui
         planes = n // getattr(self, "_traj_stride", 1) + 1
         ut = np.empty((self.nx, self.ny, planes), np.float32, order="F") if wf else None
         ui = np.empty((self.nx, self.ny, planes), np.float32, order="F") if wf else None

@@ -70,16 +70,29 @@ struct wv_ctx {
         size_t epart_cap = 0;
         float *h_signal = nullptr;                   // pinned: the device writes the energy trace straight into it
         size_t signal_cap = 0;
+        float *h_traj = nullptr;                     // the pinned buffer (one of wv_ctx::h_stream) this call's planes are copied to
+        float *d_traj = nullptr;                     // streamed calls: the slot's own device planes (the other slot's are being copied)
+        size_t traj_cap = 0;
+        hipEvent_t copy_ev = nullptr;                // the copy of the planes to h_traj has finished
         hipEvent_t ev1 = nullptr;                    // after the last device work of the call
         std::vector<hipEvent_t> kev;                 // kev[0] / kev[1] bracket the integrator launch(es); more when profiling
         bool pending = false;
         int nsteps = 0, planes = 0, impl = 0;
-        bool want_signal = false, want_fields = false, bracketed = false, resident = false;
+        bool want_signal = false, want_fields = false, streamed = false, bracketed = false, resident = false;
         int prof_launches = 0, prof_events = 0;
     } slot[2];
     int next_slot = 0;   // slot of the next wv_integrate_begin
     int n_pending = 0;   // calls begun and not ended (the oldest is slot[(next_slot + 2 - n_pending) % 2])
+    // streamed trajectories (want_fields == 2): three pinned buffers used in turn, so that the planes of a call stay
+    // readable while the next two calls are begun (two may be in flight)
+    float *h_stream[3] = {nullptr, nullptr, nullptr};
+    size_t stream_cap[3] = {0, 0, 0};
+    unsigned stream_seq = 0;
+    const float *last_view_tot = nullptr, *last_view_inc = nullptr;  // streamed trajectories of the call ended last
+    int last_view_planes = 0;
     hipStream_t up_stream = nullptr;  // uploads of the per-call tables, overlapped with the previous call's kernels
+    hipStream_t down_stream = nullptr;  // device-to-host copies of streamed trajectories (its own stream: the next call's
+                                        // kernels wait for everything on up_stream, and must not wait for these)
     hipEvent_t up_ev = nullptr;
 
     FusedPlan *fused = nullptr;
@@ -256,6 +269,7 @@ int wv_destroy(wv_ctx *c)
         if (b) (void)hipFree(b);
     if (c->d_cyl) (void)hipFree(c->d_cyl);
     if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
+    if (c->down_stream) (void)hipStreamSynchronize(c->down_stream);
     for (wv_ctx::Slot &q : c->slot) {
         if (q.d_cyl) (void)hipFree(q.d_cyl);
         if (q.h_cyl) (void)hipHostFree(q.h_cyl);
@@ -263,12 +277,17 @@ int wv_destroy(wv_ctx *c)
         if (q.h_sfac) (void)hipHostFree(q.h_sfac);
         if (q.d_epart) (void)hipFree(q.d_epart);
         if (q.h_signal) (void)hipHostFree(q.h_signal);
+        if (q.d_traj) (void)hipFree(q.d_traj);
+        if (q.copy_ev) (void)hipEventDestroy(q.copy_ev);
         for (hipEvent_t e : q.kev) (void)hipEventDestroy(e);
         if (q.ev1) (void)hipEventDestroy(q.ev1);
     }
+    for (float *b : c->h_stream)
+        if (b) (void)hipHostFree(b);
     if (c->fused) fused_destroy(c->fused);
     if (c->up_ev) (void)hipEventDestroy(c->up_ev);
     if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
+    if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return WV_OK;
@@ -327,9 +346,12 @@ int wv_create(const wv_config *cfg, const float *x, const float *y, wv_ctx **out
     CK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     CK(hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
     CK(hipEventCreateWithFlags(&c->up_ev, hipEventDisableTiming));
     CK(hipEventCreate(&c->slot[0].ev1));
     CK(hipEventCreate(&c->slot[1].ev1));
+    CK(hipEventCreateWithFlags(&c->slot[0].copy_ev, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&c->slot[1].copy_ev, hipEventDisableTiming));
     CK(hipMalloc((void **)&c->d_x, c->nx * sizeof(float)));
     CK(hipMalloc((void **)&c->d_y, c->ny * sizeof(float)));
     CK(hipMalloc((void **)&c->d_sx, c->nx * sizeof(float)));
@@ -664,9 +686,9 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     if (c->n_pending >= 2) return fail(c, WV_ERR_STATE, "wv_integrate_begin: two integrates are already pending");
     if (c->n_pending == 1) {
         const wv_ctx::Slot &o = c->slot[(c->next_slot + 1) % 2];
-        if (want_fields || o.want_fields || c->profiling)
+        if (want_fields == 1 || (o.want_fields && !o.streamed) || c->profiling)
             return fail(c, WV_ERR_STATE, "wv_integrate_begin: previous integrate not ended (a second call may only be enqueued "
-                                         "when neither call returns trajectories and profiling is off)");
+                                         "when neither call returns trajectories through the device buffer and profiling is off)");
     }
     if (!tspan || nsteps < 1) return fail(c, WV_ERR_INVALID, "wv_integrate: tspan NULL or nsteps < 1");
     if (capture && nsteps < 2 * WV_FRAMESKIP)
@@ -739,7 +761,23 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     }
     const int tstride = c->traj_stride;
     const int nplanes = nsteps / tstride + 1;  // saved times 0, stride, 2*stride, ... <= nsteps
-    if (want_fields) {
+    const bool streamed = want_fields == 2;
+    if (streamed) {  // the planes go to the slot's device buffer and from there, on the copy stream, to pinned host memory
+                     // while the NEXT call's kernels run (writing them to host memory from the step kernel itself was
+                     // measured: the PCIe bursts stall the tiles, +65 %)
+        const size_t need = (size_t)2 * nplanes * c->P;
+        const int b = (int)(c->stream_seq++ % 3u);
+        if (need > c->stream_cap[b]) {
+            if (c->h_stream[b]) (void)hipHostFree(c->h_stream[b]);
+            c->h_stream[b] = nullptr;
+            c->stream_cap[b] = 0;
+            HIPCHK(c, hipHostMalloc((void **)&c->h_stream[b], need * sizeof(float), hipHostMallocDefault));
+            c->stream_cap[b] = need;
+        }
+        q.h_traj = c->h_stream[b];
+        rc = ensure(c, &q.d_traj, &q.traj_cap, need);
+        if (rc) return rc;
+    } else if (want_fields) {
         rc = ensure(c, &c->d_traj, &c->traj_cap, (size_t)2 * nplanes * c->P);
         if (rc) return rc;
     }
@@ -753,8 +791,9 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     }
 
     g_hostprof.lap(3);
-    float *tt = want_fields ? c->d_traj : nullptr;                               // u_tot planes
-    float *ti_ = want_fields ? c->d_traj + (size_t)nplanes * c->P : nullptr;        // u_inc planes
+    float *traj = streamed ? q.d_traj : c->d_traj;
+    float *tt = want_fields ? traj : nullptr;                                    // u_tot planes
+    float *ti_ = want_fields ? traj + (size_t)nplanes * c->P : nullptr;             // u_inc planes
 
     float *cur = frame(c, 2);
     // energies of the initial state: the very partial sums the previous call ended on when the state is unchanged (the
@@ -876,12 +915,19 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     }
     c->elast_valid = want_signal != 0;
     HIPCHK(c, hipEventRecord(q.ev1, st));
+    if (streamed) {
+        HIPCHK(c, hipStreamWaitEvent(c->down_stream, q.ev1, 0));
+        HIPCHK(c, hipMemcpyAsync(q.h_traj, q.d_traj, (size_t)2 * nplanes * c->P * sizeof(float), hipMemcpyDeviceToHost,
+                                 c->down_stream));
+        HIPCHK(c, hipEventRecord(q.copy_ev, c->down_stream));
+    }
     HIPCHK(c, hipGetLastError());
 
     q.pending = true;
     q.nsteps = nsteps;
     q.want_signal = want_signal != 0;
     q.want_fields = want_fields != 0;
+    q.streamed = streamed;
     q.planes = nplanes;
     q.impl = impl;
     c->n_pending++;
@@ -902,9 +948,9 @@ int wv_integrate_end(wv_ctx *c, float *signal, float *u_tot, float *u_inc)
     const int n = q.nsteps;
     hipStream_t st = c->stream;
     const size_t tp = (size_t)q.planes * c->P;
-    if (u_tot) HIPCHK(c, hipMemcpyAsync(u_tot, c->d_traj, tp * sizeof(float), hipMemcpyDeviceToHost, st));
-    if (u_inc) HIPCHK(c, hipMemcpyAsync(u_inc, c->d_traj + tp, tp * sizeof(float), hipMemcpyDeviceToHost, st));
-    if (!u_tot && !u_inc) {
+    if (u_tot && !q.streamed) HIPCHK(c, hipMemcpyAsync(u_tot, c->d_traj, tp * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (u_inc && !q.streamed) HIPCHK(c, hipMemcpyAsync(u_inc, c->d_traj + tp, tp * sizeof(float), hipMemcpyDeviceToHost, st));
+    if ((!u_tot && !u_inc) || q.streamed) {
         // everything the caller gets is already on its way (or here): poll the call's last event for a while before
         // falling back to a blocking wait (the wake-up of a blocking wait costs more than the rest of this function)
         static const bool spin = !(getenv("WAVES_AMD_SPIN") && atoi(getenv("WAVES_AMD_SPIN")) == 0);
@@ -928,9 +974,17 @@ int wv_integrate_end(wv_ctx *c, float *signal, float *u_tot, float *u_inc)
     } else {
         HIPCHK(c, hipStreamSynchronize(st));
     }
+    if (q.streamed) HIPCHK(c, hipEventSynchronize(q.copy_ev));
     q.pending = false;
     c->n_pending--;
     if (signal) memcpy(signal, q.h_signal, (size_t)(n + 1) * 3 * sizeof(float));
+    if (q.streamed) {  // (the planes are already in host memory; callers that can read them in place use wv_integrate_end_view)
+        if (u_tot) memcpy(u_tot, q.h_traj, tp * sizeof(float));
+        if (u_inc) memcpy(u_inc, q.h_traj + tp, tp * sizeof(float));
+    }
+    c->last_view_tot = q.streamed ? q.h_traj : nullptr;
+    c->last_view_inc = q.streamed ? q.h_traj + tp : nullptr;
+    c->last_view_planes = q.streamed ? q.planes : 0;
     if (q.impl == WV_IMPL_FUSED && c->n_pending == 0) fused_dump_stamps(c->fused, st);
     c->timing = wv_timing{};
     c->timing.steps = n;
@@ -959,6 +1013,17 @@ int wv_integrate_end(wv_ctx *c, float *signal, float *u_tot, float *u_inc)
         c->timing.step_kernel_ms = sum;
         c->timing.step_kernel_launches = q.prof_launches;
     }
+    return WV_OK;
+}
+
+int wv_integrate_end_view(wv_ctx *c, float *signal, const float **u_tot, const float **u_inc, int *planes)
+{
+    int rc = wv_integrate_end(c, signal, nullptr, nullptr);
+    if (rc) return rc;
+    if (!c->last_view_tot) return fail(c, WV_ERR_STATE, "wv_integrate_end_view: the call was not begun with want_fields == 2");
+    if (u_tot) *u_tot = c->last_view_tot;
+    if (u_inc) *u_inc = c->last_view_inc;
+    if (planes) *planes = c->last_view_planes;
     return WV_OK;
 }
 

@@ -816,7 +816,14 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
     p.max_polls = (mp && atoi(mp) > 0) ? atoi(mp) : pl->max_polls;
     p.abort = pl->d_abort;
     void *args[1] = {&p};
-    const hipError_t e = hipLaunchCooperativeKernel(resident_ptr(pl), dim3((unsigned)nt), dim3(512), args, 0, s);
+    // A plain launch: the grid is at most the number of blocks the device holds at once (resident_capacity, from the
+    // occupancy query -- the same number a cooperative launch would check it against), and an ordinary launch has the same
+    // residency.  hipLaunchCooperativeKernel (WAVES_AMD_COOP=1) additionally serialises the launch against the work of
+    // every other stream of the process: the copy stream's transfers (streamed trajectories, table uploads) then no
+    // longer overlap the kernel, and each launch costs the host ~17 us more.
+    static const bool coop = getenv("WAVES_AMD_COOP") && atoi(getenv("WAVES_AMD_COOP")) != 0;
+    const hipError_t e = coop ? hipLaunchCooperativeKernel(resident_ptr(pl), dim3((unsigned)nt), dim3(512), args, 0, s)
+                              : hipLaunchKernel(resident_ptr(pl), dim3((unsigned)nt), dim3(512), args, 0, s);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         pl->resident_capacity = 0;  // do not try again

@@ -44,7 +44,7 @@ class WaveEnv:
         self.dt = f32(dt)
         self.integration_steps = int(integration_steps)
         self.actions = int(actions)
-        self.return_fields = return_fields
+        self.return_fields = return_fields        # False / True (src/env.jl:120) / "stream" (planes streamed to pinned memory)
         self.trajectory_stride = int(trajectory_stride)   # u_tot / u_inc of env(action) hold every k-th saved time
         if self.trajectory_stride != 1:
             self.ctx.set_trajectory_stride(self.trajectory_stride)
