@@ -196,6 +196,25 @@ int wv_selftest_granules(wv_ctx *ctx, int iters, unsigned long long *checked, un
 /* raw device pointer of the source shape (nx*ny floats) */
 int wv_device_source_shape(wv_ctx *ctx, void **dptr, size_t *bytes);
 
+/* ---- the batched 1-D latent dynamics of the surrogate models -------------------------------------------
+ * z = iter(z0, t, [C, F, PML]) with iter = Integrator(runge_kutta, AcousticDynamics(latent_dim, c0, pml_width, pml_scale), dt)
+ * (src/model/acoustic_energy_model.jl:89-107, 121-124; dynamics src/dynamics.jl:190-222; RK4 :9-16; Integrator :37-49):
+ *   x[n]              latent_dim.x (OneDim, src/dims.jl:48-50); n <= 1024
+ *   X (K, B), Y (n, K, B)   C = LinearInterpolation(X, Y), evaluated as linear_interp (src/utils.jl:69-98)
+ *   shape (n, B), freq      F = Source(shape, freq) called with the time vector (src/sources.jl:21-23)
+ *   PML (n, B)              sigma = dyn.pml[[1]] .* PML  (src/dynamics.jl:192-193, build_pml(::OneDim) src/pml.jl:6-15)
+ *   z0 (n, 4, B), t (steps + 1, B)   initial fields [U_tot, V_tot, U_inc, V_inc] and the tabulated times
+ *   z (n, 4, B, steps + 1)  every state (the reference's `cat(ui, ...; dims = 4)`)
+ * All arrays column-major (Julia layout), caller-owned host memory.  Stateless: no ctx.  The adjoint of this integrator
+ * (adjoint_sensitivity, src/dynamics.jl:97-128) is not provided. */
+typedef struct wv_latent_config {
+    int n, batch, knots, steps;
+    float c0, dt, pml_width, pml_scale, freq;
+    int device;
+} wv_latent_config;
+int wv_latent_integrate(const wv_latent_config *cfg, const float *x, const float *X, const float *Y, const float *shape,
+                        const float *PML, const float *z0, const float *t, float *z);
+
 #ifdef __cplusplus
 }
 #endif

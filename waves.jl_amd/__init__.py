@@ -15,6 +15,7 @@ from .dims import TwoDim, build_dirichlet, build_grid, build_wave, get_dx, get_d
 from .dynamics import AcousticDynamics, Integrator, UniformSpeed, build_tspan, runge_kutta
 from .env import (FRAMESKIP, RandomDesignPolicy, WaveEnv, WaveEnvState, action_space, is_terminated, reset, reward,
                   rollout_pipelined, state, step_all)
+from .latent import LatentIntegrator, LatentSource, LinearInterpolation, OneDim, compute_latent_energy
 from .sources import NoSource, RandomPosGaussianSource, Source
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -33,6 +33,11 @@ class wv_config(C.Structure):
                 ("pml_scale", C.c_float), ("device", C.c_int), ("impl", C.c_int)]
 
 
+class wv_latent_config(C.Structure):
+    _fields_ = [("n", C.c_int), ("batch", C.c_int), ("knots", C.c_int), ("steps", C.c_int), ("c0", C.c_float),
+                ("dt", C.c_float), ("pml_width", C.c_float), ("pml_scale", C.c_float), ("freq", C.c_float), ("device", C.c_int)]
+
+
 class wv_timing(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("step_kernel_ms", C.c_double), ("step_kernel_launches", C.c_int),
                 ("steps", C.c_int), ("impl", C.c_int), ("resident", C.c_int)]
@@ -105,6 +110,7 @@ def lib():
     _sig(L, "wv_synchronize", [ctx])
     _sig(L, "wv_device_frames", [ctx, C.POINTER(_vp), C.POINTER(C.c_size_t)])
     _sig(L, "wv_release_device_frames", [ctx])
+    _sig(L, "wv_latent_integrate", [C.POINTER(wv_latent_config), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp])
     _sig(L, "wv_selftest_granules", [ctx, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)])
     _sig(L, "wv_device_source_shape", [ctx, C.POINTER(_vp), C.POINTER(C.c_size_t)])
     _lib = L

@@ -1129,6 +1129,65 @@ int wv_selftest_granules(wv_ctx *c, int iters, unsigned long long *checked, unsi
     return WV_OK;
 }
 
+// build_pml(dim::OneDim, width, scale)[1], src/pml.jl:6-15 (what `dyn.pml[[1]]` is at src/dynamics.jl:192)
+static float pml_1d_first(const float *x, int n, float width, float scale)
+{
+    const float a0 = fabsf(x[0]), an = fabsf(x[n - 1]);
+    const float start = (a0 < an ? a0 : an) - width;
+    float v = (a0 - start > 0.0f ? a0 - start : 0.0f) / width;
+    v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    return ((v * v) * v) * scale;
+}
+
+int wv_latent_integrate(const wv_latent_config *cfg, const float *x, const float *X, const float *Y, const float *shape,
+                        const float *PML, const float *z0, const float *t, float *z)
+{
+    if (!cfg || !x || !X || !Y || !shape || !PML || !z0 || !t || !z) return fail(nullptr, WV_ERR_INVALID, "wv_latent_integrate: NULL argument");
+    const int n = cfg->n, B = cfg->batch, K = cfg->knots, steps = cfg->steps;
+    if (n < 3 || n > 1024) return fail(nullptr, WV_ERR_INVALID, "wv_latent_integrate: 3 <= n <= 1024 (one thread per cell)");
+    if (B < 1 || K < 2 || steps < 1 || !(cfg->dt > 0.0f)) return fail(nullptr, WV_ERR_INVALID, "wv_latent_integrate: bad sizes");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, WV_ERR_NO_DEVICE, "wv_latent_integrate: no HIP device; libwaves_amd has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, WV_ERR_INVALID, "wv_latent_integrate: device ordinal out of range");
+    HIPCHK(nullptr, hipSetDevice(cfg->device));
+    const size_t nB = (size_t)n * B, nz0 = nB * 4, nz = nz0 * (steps + 1), nt = (size_t)(steps + 1) * B;
+    // host tables: time factors of the source at the three stage times (fp32 argument, accurately rounded sin), times by step
+    std::vector<float> sf((size_t)steps * 3 * B), ts(nt);
+    const float hdt = 0.5f * cfg->dt;
+    for (int s = 0; s <= steps; ++s)
+        for (int b = 0; b < B; ++b) ts[(size_t)s * B + b] = t[(size_t)s + (size_t)(steps + 1) * b];   // t is (steps + 1, B) column-major
+    for (int s = 0; s < steps; ++s)
+        for (int b = 0; b < B; ++b) {
+            const float t0 = ts[(size_t)s * B + b];
+            const float tq[3] = {t0, t0 + hdt, t0 + cfg->dt};
+            for (int q = 0; q < 3; ++q) sf[((size_t)s * 3 + q) * B + b] = source_factor(tq[q], cfg->freq);
+        }
+    const size_t sizes[8] = {(size_t)K * B, nB * K, nB, nB, sf.size(), nt, nz0, nz};
+    size_t off[9] = {0};
+    for (int k = 0; k < 8; ++k) off[k + 1] = off[k] + ((sizes[k] + 63) & ~(size_t)63);
+    float *d = nullptr;
+    if (hipMalloc((void **)&d, off[8] * sizeof(float)) != hipSuccess) return fail(nullptr, WV_ERR_NOMEM, "wv_latent_integrate: out of device memory");
+    const float *src[7] = {X, Y, shape, PML, sf.data(), ts.data(), z0};
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < 7 && e == hipSuccess; ++k) e = hipMemcpy(d + off[k], src[k], sizes[k] * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        LatentArgs a{};
+        a.n = n; a.B = B; a.K = K; a.steps = steps;
+        a.ops = make_ops(std::vector<float>(x, x + n));
+        a.c0 = cfg->c0; a.dt = cfg->dt; a.hdt = hdt;
+        a.pml_scale = pml_1d_first(x, n, cfg->pml_width, cfg->pml_scale);
+        a.X = d + off[0]; a.Y = d + off[1]; a.shape = d + off[2]; a.PML = d + off[3]; a.sfac = d + off[4]; a.t = d + off[5];
+        a.z0 = d + off[6]; a.z = d + off[7];
+        launch_latent(a, nullptr);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpy(z, a.z, nz * sizeof(float), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(nullptr, WV_ERR_HIP, std::string("wv_latent_integrate: ") + hipGetErrorString(e));
+    return WV_OK;
+}
+
 int wv_device_source_shape(wv_ctx *c, void **dptr, size_t *bytes)
 {
     CHECK_CTX(c);

@@ -56,4 +56,20 @@ void launch_copy_planes(const float *state, size_t P, float *tot, float *inc, hi
 void launch_observation(const Grid &g, const float *f0, const float *f1, const float *f2, const float *G, int rx, int ry,
                         float *out, hipStream_t s);
 
+// batched 1-D latent dynamics (kernels_latent.hip); all pointers are device memory, layouts column-major as in Julia
+struct LatentArgs {
+    int n, B, K, steps;      // cells (<= 1024), batch, knots of C, integration steps
+    Ops ops;                 // gradient(dim.x)
+    float c0, dt, hdt, pml_scale;
+    const float *X;          // (K, B)        knots of C = LinearInterpolation(X, Y)
+    const float *Y;          // (n, K, B)
+    const float *shape;      // (n, B)        F = Source(shape, freq)
+    const float *PML;        // (n, B)
+    const float *sfac;       // (steps, 3, B) sin(2f0*pi*t*freq) at the three stage times of every step
+    const float *t;          // (steps + 1, B) -- stored as [step][batch]
+    const float *z0;         // (n, 4, B)
+    float *z;                // (n, 4, B, steps + 1)
+};
+void launch_latent(const LatentArgs &a, hipStream_t s);
+
 }  // namespace wv
