@@ -159,7 +159,7 @@ inline void plan_order(std::vector<TileDesc> &natural, std::vector<TileDesc> &ou
 // so tiles may carry reduced field sets -- and be taller, since a thread then carries less state per cell.  Otherwise
 // every tile is AUX_ALL.
 inline bool plan_build_tiles(HostPlan &pl, int nx, int ny, int RYF, int RYB, int RYP, const float *x, const float *y,
-                             const float *sx, const float *sy, bool reduced, bool xcd_aware, int nbands = 1)
+                             const float *sx, const float *sy, bool reduced, bool xcd_aware, int nbands = 1, int oyf_cap = 0)
 {
     pl.nx = nx;
     pl.ny = ny;
@@ -173,7 +173,20 @@ inline bool plan_build_tiles(HostPlan &pl, int nx, int ny, int RYF, int RYB, int
         if (!(x[i] > x[i - 1])) pl.monotonic = false;
     for (int j = 1; j < ny; ++j)
         if (!(y[j] > y[j - 1])) pl.monotonic = false;
-    const int OY[4] = {RYF - 2 * FT_H, RYB - 2 * FT_H, RYB - 2 * FT_H, RYP - 2 * FT_H};
+    // rows a tile of each field set owns at most: what its region holds, or less (WAVES_AMD_FUSED_OY="none,px,py,all":
+    // more, smaller tiles -- e.g. to fill every block slot of the device in the resident kernel)
+    int OY[4] = {RYF - 2 * FT_H, RYB - 2 * FT_H, RYB - 2 * FT_H, RYP - 2 * FT_H};
+    {
+        static int cap[4] = {0, 0, 0, 0};
+        static bool parsed = false;
+        if (!parsed) {
+            parsed = true;
+            if (const char *e = getenv("WAVES_AMD_FUSED_OY")) (void)sscanf(e, "%d,%d,%d,%d", &cap[0], &cap[1], &cap[2], &cap[3]);
+        }
+        for (int k = 0; k < 4; ++k)
+            if (cap[k] >= 8 && cap[k] < OY[k]) OY[k] = cap[k];
+        if (oyf_cap >= 8 && oyf_cap < OY[0]) OY[0] = oyf_cap;
+    }
     if (OY[0] < 8 || OY[1] < 8 || OY[3] < 8 || nx < 8 || ny < 8) return false;
     std::vector<int> xs, xl;
     plan_split(0, nx, FT_X - 2 * FT_H, xs, xl);

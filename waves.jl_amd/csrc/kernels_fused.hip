@@ -182,9 +182,10 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
     const FusedLds lds = lds_view(raw, NW * RPT, RYMAX);
     FusedRegs<AUX, RPT> r;
     TileCtx cx;
+    // the tile descriptor once, in scalar registers: a scalar load chain at the top of every step costs 1.3 %
+    const TileDesc t = load_tile(*p0);
     {
         const FusedParams &p = *opaque(p0);
-        const TileDesc t = load_tile(p);
         const int tid = opaque((int)threadIdx.x);
         fused_tile_init<AUX, FL, NW, RPT>(p, t, tid, cx, r);
         fused_cyl_commit<FL>(t, tid, lds, cx, fused_cyl_fetch<AUX, FL, RPT>(p, 0, t, tid, cx, r));  // steps[s].step == s
@@ -193,7 +194,6 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
     }
     for (int s = 0;; ++s) {
         const FusedParams &p = *opaque(p0);
-        const TileDesc t = load_tile(p);
         const int tid = opaque((int)threadIdx.x);
         const StepIO &io = opaque(p.steps)[s];
         // diagnostic stamps of ONE step (the middle one); p.stamps == nullptr in every normal run
@@ -550,12 +550,38 @@ void fused_state_zeroed(FusedPlan *p)
     p->frames_clean = true;
 }
 
+static int device_slots(FusedPlan *pl);
+static int resident_capacity(FusedPlan *pl);
+
 static bool ensure_tiles(FusedPlan *p, bool aux_zero)
 {
     if (p->tiles_valid && p->tiles_aux_zero == aux_zero) return true;
-    if (!plan_build_tiles(p->hp, p->g.nx, p->g.ny, p->NW * p->RF, p->NW * p->RB, p->NW * p->RP, p->x.data(),
-                          p->y.data(), p->sx.data(), p->sy.data(), aux_zero, p->xcd_aware, p->nbands))
-        return false;
+    auto build = [&](int oyf_cap) {
+        return plan_build_tiles(p->hp, p->g.nx, p->g.ny, p->NW * p->RF, p->NW * p->RB, p->NW * p->RP, p->x.data(), p->y.data(),
+                                p->sx.data(), p->sy.data(), aux_zero, p->xcd_aware, p->nbands, oyf_cap);
+    };
+    if (!build(0)) return false;
+    // Resident kernel: every block slot of the device that stays empty is lost for the whole call, and tiles one row
+    // lower are cheaper for the (pace-setting) CUs that hold two of them.  So, when the tallest interior tiles leave
+    // slots free, use interior tiles up to two rows lower as long as the tile count stays within 95 % of the slots
+    // (measured at 700^2: 467 tiles -> 478 tiles, -2 %; 500 tiles: no better; the margin keeps a few CUs for the
+    // heaviest tiles to have to themselves).
+    // (decided from the device alone, not from whether this call may run resident: both step kernels use the same tiles,
+    // so their energy partial sums -- and with them the traces -- stay bit-identical)
+    const int cap = p->nbands == 1 ? device_slots(p) : 0;
+    if (cap > 0 && (int)p->hp.tiles.size() <= cap) {
+        const int oyf = p->NW * p->RF - 2 * FT_H;
+        int best = 0, best_n = (int)p->hp.tiles.size();
+        for (int d = 1; d <= 2 && oyf - d >= 8; ++d) {
+            if (!build(oyf - d)) break;
+            const int n = (int)p->hp.tiles.size();
+            if (n > best_n && n * 100 <= cap * 95) {
+                best = oyf - d;
+                best_n = n;
+            }
+        }
+        if (!build(best)) return false;
+    }
     p->src_dirty = true;
     p->tiles_valid = true;
     p->tiles_aux_zero = aux_zero;
@@ -570,8 +596,6 @@ int fused_energy_blocks(FusedPlan *p)
 }
 
 void fused_source_changed(FusedPlan *p) { p->src_dirty = true; }
-
-static int resident_capacity(FusedPlan *pl);
 
 void fused_scratch_dirty(FusedPlan *p) { p->scratch_clean = false; }
 
@@ -744,10 +768,9 @@ static const void *resident_ptr(const FusedPlan *pl)
     }
 }
 
-// blocks of k_steps_resident the device holds at once (0: the resident path is not available)
-static int resident_capacity(FusedPlan *pl)
+// blocks of k_steps_resident the device holds at once, whether or not this context may use that kernel right now
+static int device_slots(FusedPlan *pl)
 {
-    if (!pl->use_resident || !pl->allow_resident || pl->nbands != 1) return 0;
     if (pl->resident_capacity < 0) {
         int per_cu = 0, dev = 0;
         hipDeviceProp_t prop;
@@ -761,6 +784,13 @@ static int resident_capacity(FusedPlan *pl)
         }
     }
     return pl->resident_capacity;
+}
+
+// ... and 0 when the resident path is not available to this call
+static int resident_capacity(FusedPlan *pl)
+{
+    if (!pl->use_resident || !pl->allow_resident || pl->nbands != 1) return 0;
+    return device_slots(pl);
 }
 
 int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s)
