@@ -830,20 +830,35 @@ WV_HD void fused_compute(const FusedParams &p, const TileDesc &t, int tid, const
         F2 Vyy = F2{Yu.x - Yd.x, Yu.y - Yd.y};
         bool border = false;
         if (FL & F_EDGE) {  // one-sided stencils and the Dirichlet mask, for the sides this variant was compiled with
+            // (x sides: every lane forms the one-sided value -- a broadcast read of the row's six raw values -- and the
+            // boundary lane selects it: no lane-divergent branch, so the rows of a thread still interleave; the branch
+            // with one active lane cost the same issue slots and serialised them)
             if ((FL & F_EL) && (t.edge & EDGE_L)) {
+                const F2 *v = lds.XL[BUF] + ly * 6;
+#ifndef WV_EDGE_SELECT  // (measured: selects instead of the one-lane branch are 2.5 % slower)
                 if (gx == 0) {
-                    const F2 *v = lds.XL[BUF] + ly * 6;
                     Ux = one_sided(o.f0, o.f1, o.f2, v[0], v[2], v[4]);
                     Vxx = one_sided(o.f0, o.f1, o.f2, v[1], v[3], v[5]);
                 }
+#else
+                const F2 a = one_sided(o.f0, o.f1, o.f2, v[0], v[2], v[4]), b = one_sided(o.f0, o.f1, o.f2, v[1], v[3], v[5]);
+                Ux = gx == 0 ? a : Ux;
+                Vxx = gx == 0 ? b : Vxx;
+#endif
                 border = border || gx <= 0;
             }
             if ((FL & F_ER) && (t.edge & EDGE_R)) {
+                const F2 *v = lds.XR[BUF] + ly * 6;
+#ifndef WV_EDGE_SELECT  // (measured: selects instead of the one-lane branch are 2.5 % slower)
                 if (gx == p.nx - 1) {
-                    const F2 *v = lds.XR[BUF] + ly * 6;
                     Ux = one_sided(o.b0, o.b1, o.b2, v[0], v[2], v[4]);
                     Vxx = one_sided(o.b0, o.b1, o.b2, v[1], v[3], v[5]);
                 }
+#else
+                const F2 a = one_sided(o.b0, o.b1, o.b2, v[0], v[2], v[4]), b = one_sided(o.b0, o.b1, o.b2, v[1], v[3], v[5]);
+                Ux = gx == p.nx - 1 ? a : Ux;
+                Vxx = gx == p.nx - 1 ? b : Vxx;
+#endif
                 border = border || gx >= p.nx - 1;
             }
             if ((FL & F_ET) && (t.edge & EDGE_T) && gy == 0) {

@@ -159,7 +159,8 @@ inline void plan_order(std::vector<TileDesc> &natural, std::vector<TileDesc> &ou
 // so tiles may carry reduced field sets -- and be taller, since a thread then carries less state per cell.  Otherwise
 // every tile is AUX_ALL.
 inline bool plan_build_tiles(HostPlan &pl, int nx, int ny, int RYF, int RYB, int RYP, const float *x, const float *y,
-                             const float *sx, const float *sy, bool reduced, bool xcd_aware, int nbands = 1, int oyf_cap = 0)
+                             const float *sx, const float *sy, bool reduced, bool xcd_aware, int nbands = 1, int oyf_cap = 0,
+                             int oy_cap_all = 0)
 {
     pl.nx = nx;
     pl.ny = ny;
@@ -186,6 +187,8 @@ inline bool plan_build_tiles(HostPlan &pl, int nx, int ny, int RYF, int RYB, int
         for (int k = 0; k < 4; ++k)
             if (cap[k] >= 8 && cap[k] < OY[k]) OY[k] = cap[k];
         if (oyf_cap >= 8 && oyf_cap < OY[0]) OY[0] = oyf_cap;
+        for (int k = 0; k < 4; ++k)
+            if (oy_cap_all >= 8 && oy_cap_all < OY[k]) OY[k] = oy_cap_all;
     }
     if (OY[0] < 8 || OY[1] < 8 || OY[3] < 8 || nx < 8 || ny < 8) return false;
     std::vector<int> xs, xl;
@@ -300,10 +303,13 @@ inline void plan_pair_order(HostPlan &pl, int pair_cus)
     std::sort(key.begin(), key.end());
     const std::vector<TileDesc> src = pl.tiles;
     const int C = pair_cus, alone = 2 * C - n, pairs = n - C;
+    // which of the two tiles of a CU is launched first (the older block wins the issue arbitration): the heavy one by
+    // default; WAVES_AMD_PAIR_FLIP=1 (tuning runs) the light one
+    static const bool flip = getenv("WAVES_AMD_PAIR_FLIP") && atoi(getenv("WAVES_AMD_PAIR_FLIP")) != 0;
     for (int i = 0; i < alone; ++i) pl.tiles[pairs + i] = src[key[i].second];
     for (int i = 0; i < pairs; ++i) {
-        pl.tiles[i] = src[key[alone + i].second];
-        pl.tiles[C + i] = src[key[n - 1 - i].second];
+        pl.tiles[flip ? C + i : i] = src[key[alone + i].second];
+        pl.tiles[flip ? i : C + i] = src[key[n - 1 - i].second];
     }
 }
 

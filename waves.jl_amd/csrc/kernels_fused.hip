@@ -182,6 +182,12 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
     const FusedLds lds = lds_view(raw, NW * RPT, RYMAX);
     FusedRegs<AUX, RPT> r;
     TileCtx cx;
+#if defined(WV_PRIO_SECOND)  // (experiment) the block that shares its CU with an older one loses every arbitration: raise it
+    if ((int)blockIdx.x >= WV_PRIO_SECOND) __builtin_amdgcn_s_setprio(2);
+#endif
+#if defined(WV_PRIO_NONE)    // (experiment) interior tiles above their PML partners
+    if (AUX == AUX_NONE) __builtin_amdgcn_s_setprio(2);
+#endif
     // the tile descriptor once, in scalar registers: a scalar load chain at the top of every step costs 1.3 %
     const TileDesc t = load_tile(*p0);
     {
@@ -237,6 +243,10 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
 #undef WV_STAGE
         fused_compute<AUX, FL, NW, RPT, 4>(p, t, tid, lds, cx, r, &r);
         WV_STAMP(1)
+#ifdef WV_SLEEP_CLASS  // (sensitivity experiment: ~1 us of extra time per step in the tiles of one field set)
+        if (AUX == WV_SLEEP_CLASS)
+            __builtin_amdgcn_s_sleep(WV_SLEEP_LEN);
+#endif
         // the border first: the neighbours are waiting for it
         const unsigned tag = p.tag_base + (unsigned)(s + 1);
         if (s + 1 != p.nsteps) fused_xch_store<AUX, NW, RPT>(p, tag, t, tid, r);
@@ -244,6 +254,7 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
         fused_store<AUX, NW, RPT>(p, io, t, tid, r, e);
         fused_end_step<AUX, RPT>(r);
         WV_STAMP(2)
+#ifndef WV_NO_ENERGY  // (timing experiment only)
         if (io.epart) {  // block-uniform
             const int lane = tid & 63, w = tid >> 6;
 #pragma unroll
@@ -252,6 +263,7 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
                 if (lane == 0) red[c][w] = v;
             }
         }
+#endif
         WV_STAMP(3)
         if (s + 1 == p.nsteps) {  // the last step closes itself
             lds_barrier();
@@ -280,7 +292,11 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
             if (ok) break;
             const int ab = ((tid & 63) == 0) ? __hip_atomic_load(p.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
             if (__any(ab != 0)) break;
+#ifdef WV_POLL_BACKOFF
+            __builtin_amdgcn_s_sleep(WV_POLL_BACKOFF);
+#else
             __builtin_amdgcn_s_sleep(1);
+#endif
         }
         if (!ok && (tid & 63) == 0) {
             __hip_atomic_store(p.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -556,31 +572,46 @@ static int resident_capacity(FusedPlan *pl);
 static bool ensure_tiles(FusedPlan *p, bool aux_zero)
 {
     if (p->tiles_valid && p->tiles_aux_zero == aux_zero) return true;
-    auto build = [&](int oyf_cap) {
+    auto build = [&](int oyf_cap, int oy_cap_all) {
         return plan_build_tiles(p->hp, p->g.nx, p->g.ny, p->NW * p->RF, p->NW * p->RB, p->NW * p->RP, p->x.data(), p->y.data(),
-                                p->sx.data(), p->sy.data(), aux_zero, p->xcd_aware, p->nbands, oyf_cap);
+                                p->sx.data(), p->sy.data(), aux_zero, p->xcd_aware, p->nbands, oyf_cap, oy_cap_all);
     };
-    if (!build(0)) return false;
-    // Resident kernel: every block slot of the device that stays empty is lost for the whole call, and tiles one row
-    // lower are cheaper for the (pace-setting) CUs that hold two of them.  So, when the tallest interior tiles leave
-    // slots free, use interior tiles up to two rows lower as long as the tile count stays within 95 % of the slots
-    // (measured at 700^2: 467 tiles -> 478 tiles, -2 %; 500 tiles: no better; the margin keeps a few CUs for the
-    // heaviest tiles to have to themselves).
+    if (!build(0, 0)) return false;
+    // Resident kernel: every block slot of the device that stays empty is lost for the whole call, and lower tiles are
+    // cheaper for the (pace-setting) CUs that hold two of them.
+    //  * A grid whose tallest tiles nearly fill the slots: interior tiles up to two rows lower, as long as the tile count
+    //    stays within 95 % of the slots (700^2: 467 -> 478 tiles, -2 %; 500 tiles: no better; the margin keeps a few CUs
+    //    for the heaviest tiles to have to themselves).
+    //  * A small grid (fewer tiles than half the slots): the lowest tiles that still fit, every field set alike -- a step
+    //    is a chain of latencies there, and more, smaller tiles shorten the arithmetic link (256^2: 30 -> 160 tiles, -20 %).
     // (decided from the device alone, not from whether this call may run resident: both step kernels use the same tiles,
     // so their energy partial sums -- and with them the traces -- stay bit-identical)
     const int cap = p->nbands == 1 ? device_slots(p) : 0;
-    if (cap > 0 && (int)p->hp.tiles.size() <= cap) {
+    const int n0 = (int)p->hp.tiles.size();
+    if (cap > 0 && n0 <= cap) {
         const int oyf = p->NW * p->RF - 2 * FT_H;
-        int best = 0, best_n = (int)p->hp.tiles.size();
-        for (int d = 1; d <= 2 && oyf - d >= 8; ++d) {
-            if (!build(oyf - d)) break;
-            const int n = (int)p->hp.tiles.size();
-            if (n > best_n && n * 100 <= cap * 95) {
-                best = oyf - d;
-                best_n = n;
+        int best_f = 0, best_all = 0, best_n = n0;
+        if (2 * n0 < cap) {
+            for (int c = oyf - 1; c >= 8; --c) {
+                if (!build(0, c)) break;
+                const int n = (int)p->hp.tiles.size();
+                if (n * 100 > cap * 95) break;
+                if (n > best_n) {
+                    best_all = c;
+                    best_n = n;
+                }
+            }
+        } else {
+            for (int d = 1; d <= 2 && oyf - d >= 8; ++d) {
+                if (!build(oyf - d, 0)) break;
+                const int n = (int)p->hp.tiles.size();
+                if (n > best_n && n * 100 <= cap * 95) {
+                    best_f = oyf - d;
+                    best_n = n;
+                }
             }
         }
-        if (!build(best)) return false;
+        if (!build(best_f, best_all)) return false;
     }
     p->src_dirty = true;
     p->tiles_valid = true;
