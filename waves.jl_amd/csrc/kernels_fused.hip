@@ -580,7 +580,7 @@ static bool ensure_tiles(FusedPlan *p, bool aux_zero)
     // Resident kernel: every block slot of the device that stays empty is lost for the whole call, and lower tiles are
     // cheaper for the (pace-setting) CUs that hold two of them.
     //  * A grid whose tallest tiles nearly fill the slots: interior tiles up to two rows lower, as long as the tile count
-    //    stays within 95 % of the slots (700^2: 467 -> 478 tiles, -2 %; 500 tiles: no better; the margin keeps a few CUs
+    //    stays within 96 % of the slots (700^2: 467 -> 489 tiles, -2 %; 500 tiles: no better; the margin keeps a few CUs
     //    for the heaviest tiles to have to themselves).
     //  * A small grid (fewer tiles than half the slots): the lowest tiles that still fit, every field set alike -- a step
     //    is a chain of latencies there, and more, smaller tiles shorten the arithmetic link (256^2: 30 -> 160 tiles, -20 %).
@@ -595,7 +595,7 @@ static bool ensure_tiles(FusedPlan *p, bool aux_zero)
             for (int c = oyf - 1; c >= 8; --c) {
                 if (!build(0, c)) break;
                 const int n = (int)p->hp.tiles.size();
-                if (n * 100 > cap * 95) break;
+                if (n * 100 > cap * 96) break;
                 if (n > best_n) {
                     best_all = c;
                     best_n = n;
@@ -605,7 +605,7 @@ static bool ensure_tiles(FusedPlan *p, bool aux_zero)
             for (int d = 1; d <= 2 && oyf - d >= 8; ++d) {
                 if (!build(oyf - d, 0)) break;
                 const int n = (int)p->hp.tiles.size();
-                if (n > best_n && n * 100 <= cap * 95) {
+                if (n > best_n && n * 100 <= cap * 96) {
                     best_f = oyf - d;
                     best_n = n;
                 }

@@ -126,15 +126,20 @@ def prepare_data(ep, horizon: int):
     return s, a, t, y
 
 
-def generate_episode(policy, env, *, reset: bool = True, with_states: bool = False, verbose: bool = False) -> Episode:
+def generate_episode(policy, env, *, reset: bool = True, with_states: bool = False, verbose: bool = False,
+                     in_flight: int = 2) -> Episode:
     """generate_episode!(policy, env)  src/data.jl:12-33.  `with_states=True` records `state(env)` before every action
     like the reference does (the observation is resized on the device: 256 KB per action); the default skips it, which is
-    all the energy-trace benchmarks need."""
+    all the energy-trace benchmarks need.  Without states nothing in the loop reads the wave, so two actions are kept in
+    flight (`in_flight=2`: the host prepares action k+1 while action k runs; valid for policies that do not look at the
+    wave state, like the reference's RandomDesignPolicy); `in_flight=1` is the plain sequential loop."""
     s, a, t, y = [], [], [], []
     if reset:
         env.reset()
     keep = env.return_fields
     env.return_fields = False  # the rollout discards the returned fields (src/data.jl:27)
+    depth = 1 if with_states else max(1, min(2, int(in_flight)))
+    pending = 0
     try:
         while not env.is_terminated():
             if with_states:
@@ -142,10 +147,18 @@ def generate_episode(policy, env, *, reset: bool = True, with_states: bool = Fal
             action = policy(env)
             a.append(action)
             t.append(env.build_tspan())
-            env(action)
-            y.append(np.array(env.signal))
+            env.step_begin(action)
+            pending += 1
+            if pending >= depth:
+                env.step_end()
+                pending -= 1
+                y.append(np.array(env.signal))
             if verbose:
                 print(env.time_step)
+        while pending:
+            env.step_end()
+            pending -= 1
+            y.append(np.array(env.signal))
     finally:
         env.return_fields = keep
     return Episode(s, a, t, y)
