@@ -345,8 +345,6 @@ int wv_create(const wv_config *cfg, const float *x, const float *y, wv_ctx **out
     CK(hipSetDevice(cfg->device));
     CK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
-    CK(hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
-    CK(hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
     CK(hipEventCreateWithFlags(&c->up_ev, hipEventDisableTiming));
     CK(hipEventCreate(&c->slot[0].ev1));
     CK(hipEventCreate(&c->slot[1].ev1));
@@ -700,7 +698,12 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     const int impl = c->cfg.impl == WV_IMPL_STAGED ? WV_IMPL_STAGED : WV_IMPL_FUSED;  // AUTO -> fused
     const int si = c->next_slot;
     wv_ctx::Slot &q = c->slot[si];
-    hipStream_t st = c->stream, up = c->up_stream;
+    // The copy stream is created when first needed, and only by a context that has its device to itself: HIP multiplexes
+    // the streams of a process over a few hardware queues, and with several environments per GPU (one stream each) extra
+    // streams make kernels of different environments queue behind each other (8 envs: 45 -> 35 Gcell-updates/s).
+    const bool shared = g_live_ctx[c->cfg.device & 63] > 1;
+    if (!shared && !c->up_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+    hipStream_t st = c->stream, up = (shared || !c->up_stream) ? st : c->up_stream;
 
     // per-stage coefficient tables: stage times t, t + 0.5f0*dt, t + dt (src/dynamics.jl:10-13), built in pinned memory
     // (the slot's buffers were last used by the call before the previous one, which has been ended)
@@ -740,7 +743,7 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
         if (rc) return fail(c, rc == 2 ? WV_ERR_INVALID : WV_ERR_HIP, "fused_prepare failed");
         if (fused_generation(c->fused) != c->elast_generation) c->elast_valid = false;
         c->elast_generation = fused_generation(c->fused);
-    } else {
+    } else if (up != st) {
         HIPCHK(c, hipEventRecord(c->up_ev, up));
         HIPCHK(c, hipStreamWaitEvent(st, c->up_ev, 0));
     }
@@ -916,6 +919,7 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     c->elast_valid = want_signal != 0;
     HIPCHK(c, hipEventRecord(q.ev1, st));
     if (streamed) {
+        if (!c->down_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
         HIPCHK(c, hipStreamWaitEvent(c->down_stream, q.ev1, 0));
         HIPCHK(c, hipMemcpyAsync(q.h_traj, q.d_traj, (size_t)2 * nplanes * c->P * sizeof(float), hipMemcpyDeviceToHost,
                                  c->down_stream));

@@ -586,7 +586,8 @@ static bool ensure_tiles(FusedPlan *p, bool aux_zero)
     //    is a chain of latencies there, and more, smaller tiles shorten the arithmetic link (256^2: 30 -> 160 tiles, -20 %).
     // (decided from the device alone, not from whether this call may run resident: both step kernels use the same tiles,
     // so their energy partial sums -- and with them the traces -- stay bit-identical)
-    const int cap = p->nbands == 1 ? device_slots(p) : 0;
+    static const bool autotile = !(getenv("WAVES_AMD_FUSED_AUTOTILE") && atoi(getenv("WAVES_AMD_FUSED_AUTOTILE")) == 0);
+    const int cap = (p->nbands == 1 && autotile) ? device_slots(p) : 0;
     const int n0 = (int)p->hp.tiles.size();
     if (cap > 0 && n0 <= cap) {
         const int oyf = p->NW * p->RF - 2 * FT_H;
@@ -698,7 +699,7 @@ int fused_prepare(FusedPlan *p, int slot, float *frames, float *scratch0, float 
         hipMemcpyAsync(p->d_idx[slot], p->h_idx[slot], p->idx.size() * sizeof(int), hipMemcpyHostToDevice, up) != hipSuccess)
         return 1;
     // everything uploaded so far (the caller's coefficient tables included) before anything of this call runs on s
-    if (hipEventRecord(p->up_ev[slot], up) != hipSuccess || hipStreamWaitEvent(s, p->up_ev[slot], 0) != hipSuccess) return 1;
+    if (up != s && (hipEventRecord(p->up_ev[slot], up) != hipSuccess || hipStreamWaitEvent(s, p->up_ev[slot], 0) != hipSuccess)) return 1;
     if (G && p->src_dirty) {
         if (nt > p->src_flags_cap) {
             if (p->d_src_flags) (void)hipFree(p->d_src_flags);
