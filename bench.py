@@ -201,8 +201,9 @@ def sync_device():
         torch.cuda.synchronize()
 
 
-def timed_rollout(env, policy, n_actions):
-    """n_actions x env(policy(env)) with two actions in flight (w.rollout_pipelined spelled out to collect the timings)."""
+def timed_rollout(env, policy, n_actions, in_flight=2):
+    """n_actions x env(policy(env)) with two actions in flight (w.rollout_pipelined spelled out to collect the timings);
+    in_flight = 1 is the plain `env(action)` loop."""
     sigs, kern_ms, launches, dev_ms = [], 0.0, 0, 0.0
 
     def end():
@@ -216,9 +217,10 @@ def timed_rollout(env, policy, n_actions):
 
     for k in range(n_actions):
         env.step_begin(policy(env))
-        if k > 0:
+        if k > 0 or in_flight < 2:
             end()
-    end()
+    if in_flight >= 2 and n_actions > 0:
+        end()
     return sigs, kern_ms, launches, dev_ms
 
 
@@ -264,6 +266,8 @@ def main():
                          "HIP streams); 1 = the headline: one environment, two of its actions in flight")
     ap.add_argument("--batch-envs", type=int, default=8,
                     help="extra (untimed-for-`value`) measurement at N=1: this many independent envs on the GPU (0 = skip)")
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
+                    help="actions of the one env in flight (2 = pipelined, the default; 1 = plain env(action) loop)")
     ap.add_argument("--side-configs", type=int, default=1, help="N=1: also time 2048^2 and 256^2 after the headline (0 = skip)")
     ap.add_argument("--stub-env", action="store_true", help=argparse.SUPPRESS)  # tests: rank logic without a GPU
     args = ap.parse_args()
@@ -333,7 +337,7 @@ def main():
     dev_ms = 0.0
     kern_ms, kern_launches = 0.0, 0
     if E == 1:
-        sigs, kern_ms, kern_launches, dev_ms = timed_rollout(env, policy, args.steps)
+        sigs, kern_ms, kern_launches, dev_ms = timed_rollout(env, policy, args.steps, args.in_flight)
     else:
         sigs = []
         for _ in range(args.steps):
@@ -414,7 +418,8 @@ def main():
             "config": {"workload": f"TwoDim(15.0f0, {ngrid}) + triple-ring design_space, RandomPosGaussianSource, "
                                    f"{STEPS_PER_ACTION} integration steps per env action, RandomDesignPolicy",
                        "impl": impl, "envs_per_gpu": E, "pml_width": args.pml_width,
-                       "in_flight": "2 actions of the one env (host work of action k+1 under the kernel of action k)"
+                       "in_flight": ("2 actions of the one env (host work of action k+1 under the kernel of action k)"
+                                     if args.in_flight == 2 else "1 (plain env(action) loop)")
                                     if E == 1 else "4 envs at a time on their HIP streams",
                        "device_ms_per_step": round(dev_ms / args.steps, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
