@@ -410,6 +410,9 @@ struct XchG {
     unsigned a, b, c, t;  // three value bit patterns, tag
 };
 constexpr int XCH_PLANES = 4;
+// a byte offset no exchange buffer reaches (num_records < 2^31): the buffer unit returns zeros for such a lane and drops its
+// stores, without a memory access
+constexpr unsigned XCH_OOB = 0x80000000u;
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef unsigned int wv_u4 __attribute__((ext_vector_type(4)));
 // raw buffer resource over the exchange buffer (gfx9 word 3: 32-bit data format, raw addressing); accesses carry the
@@ -461,6 +464,7 @@ WV_HD XchG xch_get(const FusedParams &p, unsigned base, unsigned off)
     const wv_u4 w = __builtin_amdgcn_raw_buffer_load_b128(xch_rsrc(p), (int)off, (int)base, 16);
     return XchG{w.x, w.y, w.z, w.w};
 #else
+    if (off >= XCH_OOB) return XchG{0u, 0u, 0u, 0u};  // (what the buffer unit does with an out-of-range lane)
     const unsigned *q = reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(p.xch) + base + off);
     return XchG{q[0], q[1], q[2], q[3]};
 #endif
@@ -585,11 +589,15 @@ WV_HD bool fused_xch_load(const FusedParams &p, unsigned tag, const TileDesc &t,
     const bool lx = r.sx != 0.0f;
     const unsigned PS = p.P * 16u;
     const unsigned base = xch_plane_offset(p, tag & 1u, 0);
-    // ---- first all the loads and the tag checks: a read that comes too early is abandoned here, before any of the
-    // register shuffling below (a failed attempt costs a wave ~40 instructions instead of ~140)
+    // ---- first all the loads, branch-free: a lane that needs nothing from a row addresses beyond the buffer's
+    // num_records (XCH_OOB) -- the buffer unit answers such a lane with zeros without touching memory -- so every
+    // granule of the halo is in flight before the first tag is looked at (with the loads under row conditions the
+    // compiler waited for each row's granules before issuing the next row's: four round trips instead of one), and
+    // a cell that is not read needs no zero of its own.  Then the tag checks: a read that comes too early is
+    // abandoned before any of the selects below.
     XchG g[RPT][NG];
     int cls[RPT];
-    bool ok = true;
+    bool needs[RPT];
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
         const int ly = w + NW * rr;
@@ -602,9 +610,8 @@ WV_HD bool fused_xch_load(const FusedParams &p, unsigned tag, const TileDesc &t,
 #else
         const bool need = inx && in_row && !own;
 #endif
+        needs[rr] = need;
         const unsigned off = ((unsigned)cgy * (unsigned)p.nx + (unsigned)cgx) * 16u;
-#pragma unroll
-        for (int k = 0; k < NG; ++k) g[rr][k] = XchG{0u, 0u, 0u, tag};
         // With reduced field sets the owner of a halo cell carries -- and sends -- an auxiliary field only where that
         // field can be non-zero (class of the cell); anywhere else its value is the exact zero the field-set invariant
         // guarantees.  AUX_PX / AUX_PY tiles only exist with reduced field sets, and their region has sigma == 0 along the
@@ -613,51 +620,49 @@ WV_HD bool fused_xch_load(const FusedParams &p, unsigned tag, const TileDesc &t,
         if (AUX == AUX_PX) cls[rr] = lx ? 1 : 0;
         if (AUX == AUX_PY) cls[rr] = p.sy[cgy] != 0.0f ? 2 : 0;
         if (AUX == AUX_ALL) cls[rr] = xch_class(p, lx, p.sy[cgy] != 0.0f);
-        if (need) {
-            const unsigned o = xch_opaque(off);
-            g[rr][0] = xch_get(p, base, o);
-            g[rr][1] = xch_get(p, base + PS, o);
-            if (NG > 2 && cls[rr] != 0) g[rr][2] = xch_get(p, base + 2 * PS, o);
-            if (NG > 3 && cls[rr] == 3) g[rr][3] = xch_get(p, base + 3 * PS, o);
-        }
+        const unsigned o = xch_opaque(need ? off : XCH_OOB);
+        g[rr][0] = xch_get(p, base, o);
+        g[rr][1] = xch_get(p, base + PS, o);
+        if (NG > 2) g[rr][2] = xch_get(p, base + 2 * PS, xch_opaque(need && cls[rr] != 0 ? off : XCH_OOB));
+        if (NG > 3) g[rr][3] = xch_get(p, base + 3 * PS, xch_opaque(need && cls[rr] == 3 ? off : XCH_OOB));
+    }
+    bool ok = true;
 #ifndef WV_XCH_NOWAIT  // (timing experiment only: results are wrong without the check)
 #pragma unroll
-        for (int k = 0; k < NG; ++k) ok = ok && g[rr][k].t == tag;
-#endif
+    for (int rr = 0; rr < RPT; ++rr) {
+        bool have = g[rr][0].t == tag && g[rr][1].t == tag;
+        if (NG > 2) have = have && (cls[rr] == 0 || g[rr][2].t == tag);
+        if (NG > 3) have = have && (cls[rr] != 3 || g[rr][3].t == tag);
+        ok = ok && (have || !needs[rr]);
 #ifdef WV_XCH_DEBUG
-        if (need && !(g[rr][0].t == tag && g[rr][1].t == tag) && wv_xch_debug)
-            printf("  slot %d aux %d x0 %d y0 %d ox %d oy %d: lane %d ly %d gx %d gy %d has tags %u %u want %u\n", t.slot, t.aux, t.x0, t.y0, t.ox, t.oy, lane, ly, gx, gy, g[rr][0].t, g[rr][1].t, tag), wv_xch_debug--;
+        if (needs[rr] && !have && wv_xch_debug)
+            printf("  slot %d aux %d x0 %d y0 %d ox %d oy %d: lane %d rr %d has tags %u %u want %u\n", t.slot, t.aux, t.x0, t.y0, t.ox, t.oy, lane, rr, g[rr][0].t, g[rr][1].t, tag), wv_xch_debug--;
 #endif
     }
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
     if (!__all(ok)) return false;   // wave-uniform: the caller polls again
 #else
     if (!ok) return false;
 #endif
-    // ---- then the new state of the step
+    // ---- then the new state of the step: own cells keep what stage 4 left in y, halo cells take the granules' values,
+    // everything else (outside the domain, beyond the region) the zeros of the out-of-range reads: one select per value
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
         const int ly = w + NW * rr;
-        const int gy = t.y0 - FT_H + ly;
-        const bool in_row = gy >= 0 && gy < p.ny && ly < t.oy + 2 * FT_H;
         const bool own = ownx && ly >= FT_H && ly < FT_H + t.oy;
-#ifdef WV_XCH_NOLOAD
-        const bool need = false && inx && in_row;
-#else
-        const bool need = inx && in_row && !own;
-#endif
         float at[3] = {0.0f, 0.0f, 0.0f}, ai[3] = {0.0f, 0.0f, 0.0f};  // Psi_x, Psi_y, Omega of the halo cell
         if (NG == 3) {
-            at[AUX == AUX_PX ? 0 : 1] = __builtin_bit_cast(float, xch_copy(g[rr][2].a));
-            ai[AUX == AUX_PX ? 0 : 1] = __builtin_bit_cast(float, xch_copy(g[rr][2].b));
+            at[AUX == AUX_PX ? 0 : 1] = __builtin_bit_cast(float, g[rr][2].a);
+            ai[AUX == AUX_PX ? 0 : 1] = __builtin_bit_cast(float, g[rr][2].b);
         } else if (NG == 4) {
             // (selects, not run-time indices: everything stays in registers)
             const int c = cls[rr];
             const XchG &h2 = g[rr][2], &h3 = g[rr][NG - 1];
-            const float a2 = __builtin_bit_cast(float, xch_copy(h2.a)), b2 = __builtin_bit_cast(float, xch_copy(h2.b));
-            const float c2 = __builtin_bit_cast(float, xch_copy(h2.c));
-            const float a3 = __builtin_bit_cast(float, xch_copy(h3.a)), b3 = __builtin_bit_cast(float, xch_copy(h3.b));
-            const float c3 = __builtin_bit_cast(float, xch_copy(h3.c));
+            const float a2 = __builtin_bit_cast(float, h2.a), b2 = __builtin_bit_cast(float, h2.b);
+            const float c2 = __builtin_bit_cast(float, h2.c);
+            const float a3 = __builtin_bit_cast(float, h3.a), b3 = __builtin_bit_cast(float, h3.b);
+            const float c3 = __builtin_bit_cast(float, h3.c);
             at[0] = (c & 1) ? a2 : 0.0f;
             ai[0] = c == 3 ? a3 : (c == 1 ? b2 : 0.0f);
             at[1] = c == 3 ? b2 : (c == 2 ? a2 : 0.0f);
@@ -668,19 +673,17 @@ WV_HD bool fused_xch_load(const FusedParams &p, unsigned tag, const TileDesc &t,
         const unsigned v0[3] = {g[rr][0].a, g[rr][0].b, g[rr][0].c}, v1[3] = {g[rr][1].a, g[rr][1].b, g[rr][1].c};
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
-            float vt = own ? r.y[rr][0][j] : 0.0f, vi = own ? r.y[rr][1][j] : 0.0f;
-            if (need) {
-                if (j < 3) {
-                    vt = __builtin_bit_cast(float, xch_copy(v0[j]));
-                    vi = __builtin_bit_cast(float, xch_copy(v1[j]));
-                } else {
-                    const int k = aux_plane(AUX, j) - 3;
-                    vt = at[k];
-                    vi = ai[k];
-                }
+            float ht, hi;
+            if (j < 3) {
+                ht = __builtin_bit_cast(float, v0[j]);
+                hi = __builtin_bit_cast(float, v1[j]);
+            } else {
+                const int k = aux_plane(AUX, j) - 3;
+                ht = at[k];
+                hi = ai[k];
             }
-            r.u[rr][0][j] = vt;
-            r.u[rr][1][j] = vi;
+            r.u[rr][0][j] = own ? r.y[rr][0][j] : ht;
+            r.u[rr][1][j] = own ? r.y[rr][1][j] : hi;
         }
     }
     return true;
