@@ -1,5 +1,5 @@
 """Register / scratch usage of each tile variant of a fused kernel compiled ALONE (diagnostic).
-usage: python tools/variant_resources.py [k_step_fused|k_steps_resident] [variant indices...]"""
+usage: python tools/variant_resources.py [k_step_fused|k_steps_resident] [variant indices...]   (extra -D flags: WV_DEFS)"""
 import os
 import re
 import subprocess
@@ -30,7 +30,7 @@ def main():
         path = os.path.join(OUT, "v%d.hip" % i)
         open(path, "w").write(src[:a] + "    RUN(%s, %s, %s); (void)fl; (void)fe; (void)cyl;\n" % (A, F, R) + src[b:])
         cmd = ("hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 -I%s -I%s/include "
-               "-c %s -o %s.o -Rpass-analysis=kernel-resource-usage 2> %s.txt" % (CS, ROOT, path, path, path))
+               "%s -c %s -o %s.o -Rpass-analysis=kernel-resource-usage 2> %s.txt" % (CS, ROOT, os.environ.get("WV_DEFS", ""), path, path, path))
         procs.append(subprocess.Popen(cmd, shell=True))
         if len(procs) >= 6:
             procs.pop(0).wait()

@@ -278,11 +278,22 @@ WV_HD float px_right(const R *nb, int lane, int rr, int k)
 #endif
 }
 
+// index of the thread's wave in its block.  Wave-uniform by construction, and said so (WV_UNIFORM_ROWS): the row tests of a
+// wave (ly = w + NW * rr against the stage's row range) then are scalar compares and branches instead of v_cmp +
+// exec-mask regions -- whose "row skipped" side needs a value for everything the region assigns
+WV_HD int wv_wave_of(int tid)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && defined(WV_UNIFORM_ROWS)
+    return __builtin_amdgcn_readfirstlane(tid >> 6);
+#else
+    return tid >> 6;
+#endif
+}
 // ---- phase 0a: what a tile keeps for all its steps -------------------------------------------------------------
 template <int AUX, int FL, int NW, int RPT>
 WV_HD void fused_tile_init(const FusedParams &p, const TileDesc &t, int tid, TileCtx &cx, FusedRegs<AUX, RPT> &r)
 {
-    const int lane = tid & 63, w = tid >> 6;
+    const int lane = tid & 63, w = wv_wave_of(tid);
     const int gx = t.x0 - FT_H + lane;
     const bool inx = gx >= 0 && gx < p.nx;
     const int cgx = gx < 0 ? 0 : (gx >= p.nx ? p.nx - 1 : gx);
@@ -335,7 +346,7 @@ template <int AUX, int NW, int RPT>
 WV_HD void fused_load_state(const FusedParams &p, const float *u, const TileDesc &t, int tid, FusedRegs<AUX, RPT> &r)
 {
     constexpr int NS = aux_ns(AUX);
-    const int lane = tid & 63, w = tid >> 6;
+    const int lane = tid & 63, w = wv_wave_of(tid);
     const int gx = t.x0 - FT_H + lane;
     const bool inx = gx >= 0 && gx < p.nx;
     const int cgx = gx < 0 ? 0 : (gx >= p.nx ? p.nx - 1 : gx);
@@ -492,6 +503,26 @@ WV_HD float wv_any(float v)
     return v * 0.0f;
 #endif
 }
+// The same with an uninitialised read: `undef` to the optimiser, which folds every merge with it to the other side (the
+// frozen form above is resolved to 0.0f, which then has to be materialised: a `v_mov_b32 v, 0` per register and step).
+// Nothing ever branches on such a value or lets it reach an output: the rows / lanes it stands in are the ones no later
+// stage reads.
+WV_HD float wv_undef(float v)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(WV_NO_ANY)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wuninitialized"
+    float x;
+    (void)v;
+    return x;
+#pragma clang diagnostic pop
+#else
+    return v * 0.0f;
+#endif
+}
+#ifndef WV_UNDEF_MASK
+#define WV_UNDEF_MASK 18  // bsq and y: free; px, acc, u: the undef form raises register pressure (spills)
+#endif
 template <int AUX, int RPT>
 WV_HD void fused_end_step(FusedRegs<AUX, RPT> &r)  // after stage 4 (y is still needed)
 {
@@ -499,15 +530,15 @@ WV_HD void fused_end_step(FusedRegs<AUX, RPT> &r)  // after stage 4 (y is still 
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r.px[rr][k] = wv_any(r.px[rr][k]);
+        for (int k = 0; k < 4; ++k) r.px[rr][k] = (WV_UNDEF_MASK & 1) ? wv_undef(r.px[rr][k]) : wv_any(r.px[rr][k]);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) r.bsq[q][rr] = wv_any(r.bsq[q][rr]);
+        for (int q = 0; q < 3; ++q) r.bsq[q][rr] = (WV_UNDEF_MASK & 2) ? wv_undef(r.bsq[q][rr]) : wv_any(r.bsq[q][rr]);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
-                r.acc[rr][s][j] = wv_any(r.acc[rr][s][j]);
-                r.u[rr][s][j] = wv_any(r.u[rr][s][j]);
+                r.acc[rr][s][j] = (WV_UNDEF_MASK & 4) ? wv_undef(r.acc[rr][s][j]) : wv_any(r.acc[rr][s][j]);
+                r.u[rr][s][j] = (WV_UNDEF_MASK & 8) ? wv_undef(r.u[rr][s][j]) : wv_any(r.u[rr][s][j]);
             }
     }
 }
@@ -520,7 +551,7 @@ WV_HD void fused_end_poll(FusedRegs<AUX, RPT> &r)  // after the halo poll (u hol
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int j = 0; j < NS; ++j) r.y[rr][s][j] = wv_any(r.y[rr][s][j]);
+            for (int j = 0; j < NS; ++j) r.y[rr][s][j] = (WV_UNDEF_MASK & 16) ? wv_undef(r.y[rr][s][j]) : wv_any(r.y[rr][s][j]);
 }
 
 // after stage 4: the tile's output cells within FT_H of the edge of its output rectangle -> exchange buffer.
@@ -531,7 +562,7 @@ WV_HD void fused_xch_store(const FusedParams &p, unsigned tag, const TileDesc &t
 {
     constexpr int NS = aux_ns(AUX);
     constexpr bool HAS_SY = AUX == AUX_PY || AUX == AUX_ALL;
-    const int lane = tid & 63, w = tid >> 6;
+    const int lane = tid & 63, w = wv_wave_of(tid);
     const int gx = t.x0 - FT_H + lane;
     const bool ownx = lane >= FT_H && lane < FT_H + t.ox;
     const bool bordx = ownx && (lane < 2 * FT_H || lane >= t.ox);
@@ -581,7 +612,7 @@ WV_HD bool fused_xch_load(const FusedParams &p, unsigned tag, const TileDesc &t,
 {
     constexpr int NS = aux_ns(AUX);
     constexpr int NG = NS == 3 ? 2 : (AUX == AUX_ALL ? 4 : 3);  // granules a halo cell of this field set may need
-    const int lane = tid & 63, w = tid >> 6;
+    const int lane = tid & 63, w = wv_wave_of(tid);
     const int gx = t.x0 - FT_H + lane;
     const bool inx = gx >= 0 && gx < p.nx && lane < t.ox + 2 * FT_H;  // (columns beyond the region belong to nobody's ring)
     const int cgx = gx < 0 ? 0 : (gx >= p.nx ? p.nx - 1 : gx);
@@ -696,7 +727,7 @@ WV_HD bool fused_xch_load(const FusedParams &p, unsigned tag, const TileDesc &t,
 template <int AUX, int NW, int RPT>
 WV_HD bool fused_xch_probe(const FusedParams &p, unsigned tag, const TileDesc &t, int tid)
 {
-    const int lane = tid & 63, w = tid >> 6;
+    const int lane = tid & 63, w = wv_wave_of(tid);
     const int gx = t.x0 - FT_H + lane;
     const bool inx = gx >= 0 && gx < p.nx && lane < t.ox + 2 * FT_H;
     const bool ownx = lane >= FT_H && lane < FT_H + t.ox;
@@ -737,7 +768,7 @@ WV_HD void fused_publish(const FusedParams &p, const TileDesc &t, int tid, const
                          FusedRegs<AUX, RPT> &r)
 {
     constexpr int BUF = (S - 1) & 1;
-    const int lane = tid & 63, w = tid >> 6;
+    const int lane = tid & 63, w = wv_wave_of(tid);
     const int rows = t.oy + 2 * FT_H;
     const float sf = cx.sf[stage_q(S)];
     const float cp = p.ops.cp;
@@ -745,7 +776,6 @@ WV_HD void fused_publish(const FusedParams &p, const TileDesc &t, int tid, const
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
         const int ly = w + NW * rr;
-        if (ly < S - 1 || ly >= rows - (S - 1)) continue;  // y_S is only needed on the region shrunk by S-1
         const float(&yin)[2][aux_ns(AUX)] = S == 1 ? r.u[rr] : r.y[rr];
         float wt = yin[0][0], wi = yin[1][0];
         if (FL & F_SRC) {  // tiles whose region misses the source's support carry g == 0: U + (+-0) == U exactly
@@ -758,6 +788,10 @@ WV_HD void fused_publish(const FusedParams &p, const TileDesc &t, int tid, const
         r.px[rr][1] = cp * wi;
         r.px[rr][2] = cp * yin[0][1];
         r.px[rr][3] = cp * yin[1][1];
+        // (the four products of a row the stage does not need are formed all the same: assigned under the row test, px
+        // would need a value on the other side of it -- a register move per product and step -- and the waves that skip
+        // rows wait at the stage barrier for those that do not anyway)
+        if (ly < S - 1 || ly >= rows - (S - 1)) continue;  // y_S is only needed on the region shrunk by S-1
         lds.W[BUF][i] = F2{r.px[rr][0], r.px[rr][1]};
         lds.Vy[BUF][i] = F2{cp * yin[0][2], cp * yin[1][2]};
         if (FL & F_EDGE) {  // raw copies of the three cells next to a domain boundary (sides compiled in per variant)
@@ -790,7 +824,7 @@ WV_HD void fused_speed(const FusedParams &p, const TileDesc &t, int tid, const F
                        FusedRegs<AUX, RPT> &r)
 {
     if (!(FL & F_CYL)) return;
-    const int w = tid >> 6;
+    const int w = wv_wave_of(tid);
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -814,7 +848,7 @@ WV_HD void fused_compute(const FusedParams &p, const TileDesc &t, int tid, const
     constexpr int BUF = (S - 1) & 1;
     constexpr bool HAS_SX = AUX == AUX_PX || AUX == AUX_ALL;
     constexpr bool HAS_SY = AUX == AUX_PY || AUX == AUX_ALL;
-    const int lane = tid & 63, w = tid >> 6;
+    const int lane = tid & 63, w = wv_wave_of(tid);
     const int rows = t.oy + 2 * FT_H;
     const int gx = t.x0 - FT_H + lane;
     const Ops &o = p.ops;
@@ -950,7 +984,7 @@ WV_HD void fused_store(const FusedParams &p, const StepIO &io, const TileDesc &t
                        float e[3])
 {
     constexpr int NS = aux_ns(AUX);
-    const int lane = tid & 63, w = tid >> 6;
+    const int lane = tid & 63, w = wv_wave_of(tid);
     e[0] = e[1] = e[2] = 0.0f;
     if (lane < FT_H || lane >= FT_H + t.ox) return;
     const int gx = t.x0 - FT_H + lane;

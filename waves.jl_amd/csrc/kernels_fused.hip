@@ -190,6 +190,14 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
 #endif
     // the tile descriptor once, in scalar registers: a scalar load chain at the top of every step costs 1.3 %
     const TileDesc t = load_tile(*p0);
+#ifndef WV_TID_SPILLED  // (the first version, kept for A/B)
+    // The thread index of a step is put together from the wave's index (a scalar) and the lane number: threadIdx.x itself,
+    // live around the step loop, was kept in scratch and reloaded -- with a full wait -- at the top of every step.
+    const int wave_base = __builtin_amdgcn_readfirstlane((int)threadIdx.x & ~63);
+#define WV_TID() (wave_base | (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
+#else
+#define WV_TID() opaque((int)threadIdx.x)
+#endif
     {
         const FusedParams &p = *opaque(p0);
         const int tid = opaque((int)threadIdx.x);
@@ -200,7 +208,7 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
     }
     for (int s = 0;; ++s) {
         const FusedParams &p = *opaque(p0);
-        const int tid = opaque((int)threadIdx.x);
+        const int tid = opaque(WV_TID());
         const StepIO &io = opaque(p.steps)[s];
         // diagnostic stamps of ONE step (the middle one); p.stamps == nullptr in every normal run
         unsigned long long *st = (p.stamps && s == p.nsteps / 2) ? p.stamps + (size_t)t.slot * 16 : nullptr;
@@ -256,7 +264,7 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
         WV_STAMP(2)
 #ifndef WV_NO_ENERGY  // (timing experiment only)
         if (io.epart) {  // block-uniform
-            const int lane = tid & 63, w = tid >> 6;
+            const int lane = tid & 63, w = wv_wave_of(tid);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float v = wave_sum(e[c]);
@@ -330,6 +338,7 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
             st[13] = (unsigned long long)(t.aux | (t.edge << 4));
         }
 #undef WV_STAMP
+#undef WV_TID
     }
 }
 
