@@ -520,6 +520,19 @@ WV_HD float wv_undef(float v)
     return v * 0.0f;
 #endif
 }
+// A register with arbitrary content and no instruction behind it (an empty asm "defines" it): the other side of a merge
+// with an assignment made under a row test.  Unlike the two above the optimiser cannot resolve it to a constant, and its
+// live range starts here -- so it is placed right in front of the test.
+WV_HD float wv_fresh()
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(WV_NO_ANY)
+    float x;
+    asm volatile("" : "=v"(x));
+    return x;
+#else
+    return 0.0f;
+#endif
+}
 #ifndef WV_UNDEF_MASK
 #define WV_UNDEF_MASK 18  // bsq and y: free; px, acc, u: the undef form raises register pressure (spills)
 #endif
@@ -565,7 +578,7 @@ WV_HD void fused_xch_store(const FusedParams &p, unsigned tag, const TileDesc &t
     const int lane = tid & 63, w = wv_wave_of(tid);
     const int gx = t.x0 - FT_H + lane;
     const bool ownx = lane >= FT_H && lane < FT_H + t.ox;
-    const bool bordx = ownx && (lane < 2 * FT_H || lane >= t.ox);
+    const bool edgex = lane < 2 * FT_H || lane >= t.ox;
     const bool lx = r.sx != 0.0f;
     const unsigned PS = p.P * 16u;
     const unsigned base = xch_plane_offset(p, tag & 1u, 0);
@@ -578,7 +591,7 @@ WV_HD void fused_xch_store(const FusedParams &p, unsigned tag, const TileDesc &t
         const unsigned row = (unsigned)gy * (unsigned)p.nx;
         const unsigned off = (row + (unsigned)gx) * 16u;  // byte offset in a plane: 16*P < 2^32
         const float(&y)[2][NS] = r.y[rr];
-        const bool mine = rowb ? ownx : bordx;
+        const bool mine = ownx && (rowb || edgex);  // (plain mask algebra: a select between the two masks became a v_cndmask chain)
 #ifdef WV_XCH_NOSTORE  // (timing experiment only)
         (void)off; (void)mine; (void)base; (void)PS; (void)lx;
         continue;
@@ -855,6 +868,14 @@ WV_HD void fused_compute(const FusedParams &p, const TileDesc &t, int tid, const
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
         const int ly = w + NW * rr;
+#ifdef WV_FRESH_ACC
+        if (S == 1) {  // (k1 opens the accumulator: nothing of the previous step is carried into the row test)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < NS; ++j) r.acc[rr][s][j] = wv_fresh();
+        }
+#endif
         if (ly < S || ly >= rows - S) continue;  // k_S is only needed on the region shrunk by S
         const int gy = t.y0 - FT_H + ly;
         if ((FL & (F_ET | F_EB)) && (gy < 0 || gy >= p.ny)) continue;
