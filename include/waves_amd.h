@@ -205,8 +205,7 @@ int wv_device_source_shape(wv_ctx *ctx, void **dptr, size_t *bytes);
  *   PML (n, B)              sigma = dyn.pml[[1]] .* PML  (src/dynamics.jl:192-193, build_pml(::OneDim) src/pml.jl:6-15)
  *   z0 (n, 4, B), t (steps + 1, B)   initial fields [U_tot, V_tot, U_inc, V_inc] and the tabulated times
  *   z (n, 4, B, steps + 1)  every state (the reference's `cat(ui, ...; dims = 4)`)
- * All arrays column-major (Julia layout), caller-owned host memory.  Stateless: no ctx.  The adjoint of this integrator
- * (adjoint_sensitivity, src/dynamics.jl:97-128) is not provided. */
+ * All arrays column-major (Julia layout), caller-owned host memory.  Stateless: no ctx. */
 typedef struct wv_latent_config {
     int n, batch, knots, steps;
     float c0, dt, pml_width, pml_scale, freq;
@@ -214,6 +213,20 @@ typedef struct wv_latent_config {
 } wv_latent_config;
 int wv_latent_integrate(const wv_latent_config *cfg, const float *x, const float *X, const float *Y, const float *shape,
                         const float *PML, const float *z0, const float *t, float *z);
+
+/* adjoint_sensitivity(iter, z, t, theta, dL_dz)  (src/dynamics.jl:97-121) and with it the pullback of
+ * `Flux.ChainRulesCore.rrule(iter::Integrator, z0, t, theta)` (:123-128): the reverse sweep over every saved time -- the
+ * last one included, as the reference writes it -- of the vector-Jacobian product of one runge_kutta call.
+ *   z, adj (n, 4, B, steps + 1)   the solution wv_latent_integrate returned and dL/dz
+ *   gz0 (n, 4, B)                 dL/dz0
+ *   gY (n, K, B), gshape (n, B), gPML (n, B)   the parts of dL/dtheta the reference's models train through this call:
+ *                                 C.Y (LinearInterpolation trains Y only, src/utils.jl:94), F.shape, PML.  (Zygote also
+ *                                 returns cotangents for C.X and F.freq; nothing upstream consumes them.)
+ * The products are written out by hand (the reference gets them from Zygote): same mathematics, summation order this
+ * library's own. */
+int wv_latent_adjoint(const wv_latent_config *cfg, const float *x, const float *X, const float *Y, const float *shape,
+                      const float *PML, const float *z, const float *t, const float *adj, float *gz0, float *gY,
+                      float *gshape, float *gPML);
 
 #ifdef __cplusplus
 }

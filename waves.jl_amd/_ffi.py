@@ -111,6 +111,7 @@ def lib():
     _sig(L, "wv_device_frames", [ctx, C.POINTER(_vp), C.POINTER(C.c_size_t)])
     _sig(L, "wv_release_device_frames", [ctx])
     _sig(L, "wv_latent_integrate", [C.POINTER(wv_latent_config), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp])
+    _sig(L, "wv_latent_adjoint", [C.POINTER(wv_latent_config)] + [_fp] * 12)
     _sig(L, "wv_selftest_granules", [ctx, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)])
     _sig(L, "wv_device_source_shape", [ctx, C.POINTER(_vp), C.POINTER(C.c_size_t)])
     _lib = L

@@ -1192,6 +1192,60 @@ int wv_latent_integrate(const wv_latent_config *cfg, const float *x, const float
     return WV_OK;
 }
 
+int wv_latent_adjoint(const wv_latent_config *cfg, const float *x, const float *X, const float *Y, const float *shape,
+                      const float *PML, const float *z, const float *t, const float *adj, float *gz0, float *gY,
+                      float *gshape, float *gPML)
+{
+    if (!cfg || !x || !X || !Y || !shape || !PML || !z || !t || !adj || !gz0 || !gY || !gshape || !gPML)
+        return fail(nullptr, WV_ERR_INVALID, "wv_latent_adjoint: NULL argument");
+    const int n = cfg->n, B = cfg->batch, K = cfg->knots, steps = cfg->steps;
+    if (n < 3 || n > 1024) return fail(nullptr, WV_ERR_INVALID, "wv_latent_adjoint: 3 <= n <= 1024 (one thread per cell)");
+    if (B < 1 || K < 2 || steps < 1 || !(cfg->dt > 0.0f)) return fail(nullptr, WV_ERR_INVALID, "wv_latent_adjoint: bad sizes");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, WV_ERR_NO_DEVICE, "wv_latent_adjoint: no HIP device; libwaves_amd has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, WV_ERR_INVALID, "wv_latent_adjoint: device ordinal out of range");
+    HIPCHK(nullptr, hipSetDevice(cfg->device));
+    const size_t nB = (size_t)n * B, nz0 = nB * 4, nz = nz0 * (steps + 1), nt = (size_t)(steps + 1) * B;
+    // the sweep applies the step's pullback at EVERY saved time (src/dynamics.jl:101): steps + 1 rows of time factors
+    std::vector<float> sf((size_t)(steps + 1) * 3 * B), ts(nt);
+    const float hdt = 0.5f * cfg->dt;
+    for (int s = 0; s <= steps; ++s)
+        for (int b = 0; b < B; ++b) {
+            const float t0 = t[(size_t)s + (size_t)(steps + 1) * b];
+            ts[(size_t)s * B + b] = t0;
+            const float tq[3] = {t0, t0 + hdt, t0 + cfg->dt};
+            for (int q = 0; q < 3; ++q) sf[((size_t)s * 3 + q) * B + b] = source_factor(tq[q], cfg->freq);
+        }
+    // inputs X Y shape PML sf ts z adj | outputs gz0 gY gshape gPML
+    const size_t sizes[12] = {(size_t)K * B, nB * K, nB, nB, sf.size(), nt, nz, nz, nz0, nB * K, nB, nB};
+    size_t off[13] = {0};
+    for (int k = 0; k < 12; ++k) off[k + 1] = off[k] + ((sizes[k] + 63) & ~(size_t)63);
+    float *d = nullptr;
+    if (hipMalloc((void **)&d, off[12] * sizeof(float)) != hipSuccess) return fail(nullptr, WV_ERR_NOMEM, "wv_latent_adjoint: out of device memory");
+    const float *src[8] = {X, Y, shape, PML, sf.data(), ts.data(), z, adj};
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < 8 && e == hipSuccess; ++k) e = hipMemcpy(d + off[k], src[k], sizes[k] * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d + off[9], 0, sizes[9] * sizeof(float));
+    if (e == hipSuccess) {
+        LatentAdjArgs a{};
+        a.f.n = n; a.f.B = B; a.f.K = K; a.f.steps = steps;
+        a.f.ops = make_ops(std::vector<float>(x, x + n));
+        a.f.c0 = cfg->c0; a.f.dt = cfg->dt; a.f.hdt = hdt;
+        a.f.pml_scale = pml_1d_first(x, n, cfg->pml_width, cfg->pml_scale);
+        a.f.X = d + off[0]; a.f.Y = d + off[1]; a.f.shape = d + off[2]; a.f.PML = d + off[3]; a.f.sfac = d + off[4]; a.f.t = d + off[5];
+        a.f.z0 = nullptr; a.f.z = d + off[6];
+        a.adj = d + off[7]; a.gz0 = d + off[8]; a.gY = d + off[9]; a.gshape = d + off[10]; a.gPML = d + off[11];
+        launch_latent_adjoint(a, nullptr);
+        e = hipGetLastError();
+        float *dst[4] = {gz0, gY, gshape, gPML};
+        for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipMemcpy(dst[k], d + off[8 + k], sizes[8 + k] * sizeof(float), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(nullptr, WV_ERR_HIP, std::string("wv_latent_adjoint: ") + hipGetErrorString(e));
+    return WV_OK;
+}
+
 int wv_device_source_shape(wv_ctx *c, void **dptr, size_t *bytes)
 {
     CHECK_CTX(c);

@@ -72,4 +72,16 @@ struct LatentArgs {
 };
 void launch_latent(const LatentArgs &a, hipStream_t s);
 
+// reverse sweep of adjoint_sensitivity (src/dynamics.jl:97-121) over the same dynamics
+struct LatentAdjArgs {
+    LatentArgs f;            // sizes, operators, theta; f.sfac holds (steps + 1, 3, B) -- the sweep also visits the last saved time;
+                             // f.z = the forward solution (read), f.z0 unused
+    const float *adj;        // (n, 4, B, steps + 1)  dL/dz
+    float *gz0;              // (n, 4, B)
+    float *gY;               // (n, K, B)   zero on entry
+    float *gshape;           // (n, B)
+    float *gPML;             // (n, B)
+};
+void launch_latent_adjoint(const LatentAdjArgs &a, hipStream_t s);
+
 }  // namespace wv

@@ -69,6 +69,40 @@ class LatentIntegrator:
         return z
 
 
+    def adjoint_sensitivity(self, z, t, theta, dL_dz):
+        """adjoint_sensitivity(iter, z, t, theta, dL_dz), src/dynamics.jl:97-121 -> (dL_dz0 (n, 4, B), grads) with
+        grads = {"Y": (n, K, B), "shape": (n, B), "PML": (n, B)}: the parts of theta the reference's models train."""
+        Cint, F, PML = theta
+        n = len(self.dim.x)
+        z = np.asfortranarray(z, dtype=f32)
+        adj = np.asfortranarray(dL_dz, dtype=f32)
+        t = np.asfortranarray(t, dtype=f32)
+        B, steps = z.shape[2], t.shape[0] - 1
+        PML = np.asfortranarray(PML, dtype=f32)
+        assert z.shape == (n, 4, B, steps + 1) and adj.shape == z.shape and t.shape == (steps + 1, B) and PML.shape == (n, B)
+        assert Cint.Y.shape[0] == n and Cint.X.shape[1] == B and F.shape.shape == (n, B)
+        K = Cint.X.shape[0]
+        cfg = _ffi.wv_latent_config(n, B, K, steps, float(self.c0), float(self.dt), float(self.pml_width),
+                                    float(self.pml_scale), float(F.freq), int(self.device))
+        gz0 = np.empty((n, 4, B), f32, order="F")
+        gY = np.empty((n, K, B), f32, order="F")
+        gsh = np.empty((n, B), f32, order="F")
+        gp = np.empty((n, B), f32, order="F")
+        L = _ffi.lib()
+        x = np.ascontiguousarray(self.dim.x, f32)
+        rc = L.wv_latent_adjoint(C.byref(cfg), _ffi.fptr(x), _ffi.fptr(Cint.X), _ffi.fptr(Cint.Y), _ffi.fptr(F.shape),
+                                 _ffi.fptr(PML), _ffi.fptr(z), _ffi.fptr(t), _ffi.fptr(adj), _ffi.fptr(gz0), _ffi.fptr(gY),
+                                 _ffi.fptr(gsh), _ffi.fptr(gp))
+        if rc != _ffi.WV_OK:
+            raise _ffi.WavesAmdError(rc, (L.wv_last_error(None) or b"").decode())
+        return gz0, {"Y": gY, "shape": gsh, "PML": gp}
+
+    def rrule(self, z0, t, theta):
+        """Flux.ChainRulesCore.rrule(iter::Integrator, z0, t, theta), src/dynamics.jl:123-128: (z, back)."""
+        z = self(z0, t, theta)
+        return z, (lambda adj: self.adjoint_sensitivity(z, t, theta, adj))
+
+
 def compute_latent_energy(z, dx):
     """src/model/acoustic_energy_model.jl:6-15 -> (steps + 1, 3, B)."""
     tot, inc = z[:, 0, :, :], z[:, 2, :, :]
