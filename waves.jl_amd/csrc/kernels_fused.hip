@@ -586,17 +586,17 @@ static bool ensure_tiles(FusedPlan *p, bool aux_zero)
                                 p->sx.data(), p->sy.data(), aux_zero, p->xcd_aware, p->nbands, oyf_cap, oy_cap_all);
     };
     if (!build(0, 0)) return false;
-    // Resident kernel: every block slot of the device that stays empty is lost for the whole call, and lower tiles are
-    // cheaper for the (pace-setting) CUs that hold two of them.
-    //  * A grid whose tallest tiles nearly fill the slots: interior tiles up to two rows lower, as long as the tile count
-    //    stays within 96 % of the slots (700^2: 467 -> 489 tiles, -2 %; 500 tiles: no better; the margin keeps a few CUs
-    //    for the heaviest tiles to have to themselves).
-    //  * A small grid (fewer tiles than half the slots): the lowest tiles that still fit, every field set alike -- a step
-    //    is a chain of latencies there, and more, smaller tiles shorten the arithmetic link (256^2: 30 -> 160 tiles, -20 %).
+    // Resident kernel, small grids (fewer tiles than half the device's block slots): the lowest tiles that still fit,
+    // every field set alike -- a step is a chain of latencies there, and more, smaller tiles shorten the arithmetic link
+    // and put more CUs to work (256^2: 26 -> 90 tiles, +25 %; 384^2 +22 %; 500^2 +11 %).
+    // Larger grids keep the tallest tiles the registers hold.  (Round 2 first also lowered the interior tiles of grids
+    // that nearly fill the slots by up to two rows -- 700^2: 467 -> 489 tiles, -2 % at the time; with the cheaper halo
+    // read of the final kernel the taller tiles win again: 700^2 +1.2 %, 600^2 +7 %.  WAVES_AMD_FUSED_AUTOTILE=2 brings
+    // that rule back for experiments, =0 switches both off.)
     // (decided from the device alone, not from whether this call may run resident: both step kernels use the same tiles,
     // so their energy partial sums -- and with them the traces -- stay bit-identical)
-    static const bool autotile = !(getenv("WAVES_AMD_FUSED_AUTOTILE") && atoi(getenv("WAVES_AMD_FUSED_AUTOTILE")) == 0);
-    const int cap = (p->nbands == 1 && autotile) ? device_slots(p) : 0;
+    static const int autotile = getenv("WAVES_AMD_FUSED_AUTOTILE") ? atoi(getenv("WAVES_AMD_FUSED_AUTOTILE")) : 1;
+    const int cap = (p->nbands == 1 && autotile != 0) ? device_slots(p) : 0;
     const int n0 = (int)p->hp.tiles.size();
     if (cap > 0 && n0 <= cap) {
         const int oyf = p->NW * p->RF - 2 * FT_H;
@@ -611,7 +611,7 @@ static bool ensure_tiles(FusedPlan *p, bool aux_zero)
                     best_n = n;
                 }
             }
-        } else {
+        } else if (autotile == 2) {
             for (int d = 1; d <= 2 && oyf - d >= 8; ++d) {
                 if (!build(oyf - d, 0)) break;
                 const int n = (int)p->hp.tiles.size();
