@@ -1024,10 +1024,12 @@ WV_HD void fused_store(const FusedParams &p, const StepIO &io, const TileDesc &t
                     store_out(plane + id, r.y[rr][s][j]);
                 }
         }
+        // (the energy sums are this project's own arithmetic -- the reference leaves their order open, src/env.jl:105-111 --
+        // so the fused multiply-add is used here: 4 instead of 7 instructions per cell)
         const float ut = r.y[rr][0][0], ui = r.y[rr][1][0], us = ut - ui;
-        e[0] += ut * ut;
-        e[1] += ui * ui;
-        e[2] += us * us;
+        e[0] = __builtin_fmaf(ut, ut, e[0]);
+        e[1] = __builtin_fmaf(ui, ui, e[1]);
+        e[2] = __builtin_fmaf(us, us, e[2]);
         if (io.traj_tot) io.traj_tot[id] = ut;
         if (io.traj_inc) io.traj_inc[id] = ui;
     }

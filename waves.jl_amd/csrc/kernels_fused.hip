@@ -843,6 +843,16 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
     // earlier tile decomposition -- can never be mistaken for the ones a step waits for
     const size_t xwords = (size_t)2 * XCH_PLANES * 2 * pl->g.P;  // 8-byte words: 2 parities x 4 planes x P granules of 16 bytes
     if (!pl->d_xch || pl->tag_base > 0xFFFF0000u - (unsigned)nsteps) {
+        // (Experiment knob WAVES_AMD_XCH_ALLOC=3 / 1: uncached / fine-grained device memory for the exchange buffer.  Uncached
+        // shortens a step by 0.8 % at 700^2 (profiles/r02/ab_xalloc.txt) but is NOT the default: with it a later context of
+        // the same process returned wrong trajectory planes in tests/test_gpu_parity.py -- memory handed back by hipFree
+        // after an uncached allocation did not behave like ordinary device memory on ROCm 7.2.)
+        static const int xalloc = getenv("WAVES_AMD_XCH_ALLOC") ? atoi(getenv("WAVES_AMD_XCH_ALLOC")) : 0;
+        if (!pl->d_xch && xalloc &&
+            hipExtMallocWithFlags((void **)&pl->d_xch, xwords * sizeof(unsigned long long), (unsigned)xalloc) != hipSuccess) {
+            (void)hipGetLastError();
+            pl->d_xch = nullptr;
+        }
         if (!pl->d_xch && hipMalloc((void **)&pl->d_xch, xwords * sizeof(unsigned long long)) != hipSuccess) {
             (void)hipGetLastError();
             pl->resident_capacity = 0;
