@@ -1,6 +1,7 @@
 // Microbenchmark (diagnostic): issue rate of plain and packed fp32 VALU ops on gfx950 at 1/2/4 waves per SIMD.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef float float2v __attribute__((ext_vector_type(2)));
 
 template <int MODE>
@@ -95,7 +96,7 @@ __global__ void k(float *out, int iters, unsigned long long *cyc)
 template <int MODE>
 void run(const char *name, int threads, float *d_out, unsigned long long *d_cyc)
 {
-    const int iters = 2000, blocks = 256;
+    const int iters = getenv("ITERS") ? atoi(getenv("ITERS")) : 2000, blocks = 256;  // ITERS=100000: kernels long enough for the clocks to ramp
     hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(threads), 0, 0, d_out, iters, d_cyc);
     hipDeviceSynchronize();
     hipEvent_t e0, e1;

@@ -868,7 +868,7 @@ WV_HD void fused_compute(const FusedParams &p, const TileDesc &t, int tid, const
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
         const int ly = w + NW * rr;
-#ifdef WV_FRESH_ACC
+#ifndef WV_NO_FRESH_ACC  // (default since the end of round 2: 24 fewer v_mov_b32 v, 0 per wave and step)
         if (S == 1) {  // (k1 opens the accumulator: nothing of the previous step is carried into the row test)
 #pragma unroll
             for (int s = 0; s < 2; ++s)
