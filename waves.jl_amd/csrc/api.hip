@@ -878,10 +878,9 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
         HIPCHK(c, hipEventRecord(q.kev[1], st));  // (whole chain of stage kernels: total_ms of the call)
     } else if (impl == WV_IMPL_FUSED && !c->profiling) {
         // the integrator launch(es) of the call between two events: for the resident path that is exactly the one kernel
-        HIPCHK(c, hipEventRecord(q.kev[0], st));
-        if (fused_run(c->fused, si, fcall, c->fsteps.data(), (int)c->fsteps.size(), st) != 0)
+        // (the resident launch carries the two events itself: no event packets between consecutive actions)
+        if (fused_run(c->fused, si, fcall, c->fsteps.data(), (int)c->fsteps.size(), st, q.kev[0], q.kev[1]) != 0)
             return fail(c, WV_ERR_HIP, std::string("fused_run failed: ") + hipGetErrorString(hipGetLastError()));
-        HIPCHK(c, hipEventRecord(q.kev[1], st));
         q.bracketed = true;
         q.resident = fused_last_resident(c->fused);
         if (q.resident) q.prof_launches = 1;

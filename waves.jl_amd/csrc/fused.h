@@ -54,7 +54,8 @@ void fused_source_changed(FusedPlan *p);  // the source shape was replaced
 void fused_launch(FusedPlan *p, int slot, const FusedCall &call, int step, const FusedStep &st, hipStream_t s);
 // all steps of a call: one launch of the resident kernel when the tiles fit the device at once, else a cached hipGraph of
 // single-step kernel nodes (WAVES_AMD_FUSED_GRAPH=0: eager launches).  Returns 0 on success.
-int fused_run(FusedPlan *p, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s);
+int fused_run(FusedPlan *p, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s,
+              hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);  // the events bracket the integrator launch(es)
 // After the stream has been waited for: 0, or 1 when the resident kernel of the last fused_run abandoned the call (a tile
 // waited in vain for its neighbours -- the state is then invalid; the protocol has been reset).
 int fused_finish(FusedPlan *p, int slot, hipStream_t s);
@@ -66,7 +67,8 @@ bool fused_last_resident(const FusedPlan *p);  // the last fused_run took the si
 // path (more tiles than the device holds at once, a single step, diagnostics ...; the caller then launches step by
 // step), 1 on a HIP error.  fused_run tries this first.
 void fused_allow_resident(FusedPlan *p, bool allow);  // per call: false keeps this call on the single-step kernels
-int fused_try_resident(FusedPlan *p, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s);
+int fused_try_resident(FusedPlan *p, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s,
+                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void fused_variant_counts(const FusedPlan *p, int out[4]);  // tiles per field set: NONE, PX, PY, ALL
 
 }  // namespace wv

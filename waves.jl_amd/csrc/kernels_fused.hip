@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "fused.h"
 #include "fused_plan.h"
 
@@ -834,7 +836,8 @@ static int resident_capacity(FusedPlan *pl)
     return device_slots(pl);
 }
 
-int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s)
+int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s,
+                       hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     pl->cur = slot;
     const size_t nt = pl->hp.tiles.size();
@@ -903,8 +906,22 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
     // every other stream of the process: the copy stream's transfers (streamed trajectories, table uploads) then no
     // longer overlap the kernel, and each launch costs the host ~17 us more.
     static const bool coop = getenv("WAVES_AMD_COOP") && atoi(getenv("WAVES_AMD_COOP")) != 0;
-    const hipError_t e = coop ? hipLaunchCooperativeKernel(resident_ptr(pl), dim3((unsigned)nt), dim3(512), args, 0, s)
-                              : hipLaunchKernel(resident_ptr(pl), dim3((unsigned)nt), dim3(512), args, 0, s);
+    // With a pair of events the launch carries them itself (hipExtLaunchKernel: the events take the kernel's own start and
+    // end timestamps): two hipEventRecord calls -- two barrier packets between consecutive actions -- less per action, and
+    // the measured duration is the kernel's, without the gap between an event packet and the dispatch behind it.
+    // (WAVES_AMD_EXT_EVENTS=0: separate event records around a plain launch, as before -- A/B)
+    static const bool ext = !(getenv("WAVES_AMD_EXT_EVENTS") && atoi(getenv("WAVES_AMD_EXT_EVENTS")) == 0);
+    hipError_t e;
+    if (coop || !ext) {
+        if (ev_start) (void)hipEventRecord(ev_start, s);
+        e = coop ? hipLaunchCooperativeKernel(resident_ptr(pl), dim3((unsigned)nt), dim3(512), args, 0, s)
+                 : hipLaunchKernel(resident_ptr(pl), dim3((unsigned)nt), dim3(512), args, 0, s);
+        if (ev_stop && e == hipSuccess) (void)hipEventRecord(ev_stop, s);
+    } else if (ev_start && ev_stop) {
+        e = hipExtLaunchKernel(resident_ptr(pl), dim3((unsigned)nt), dim3(512), args, 0, s, ev_start, ev_stop, 0);
+    } else {
+        e = hipLaunchKernel(resident_ptr(pl), dim3((unsigned)nt), dim3(512), args, 0, s);
+    }
     if (e != hipSuccess) {
         (void)hipGetLastError();
         pl->resident_capacity = 0;  // do not try again
@@ -933,12 +950,24 @@ int fused_finish(FusedPlan *pl, int slot, hipStream_t s)
     return 1;
 }
 
-int fused_run(FusedPlan *pl, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s)
+static int fused_run_steps(FusedPlan *pl, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s, hipEvent_t ev_start);
+
+int fused_run(FusedPlan *pl, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s, hipEvent_t ev_start,
+              hipEvent_t ev_stop)
 {
-    const int rr = fused_try_resident(pl, slot, call, steps, nsteps, s);
+    const int rr = fused_try_resident(pl, slot, call, steps, nsteps, s, ev_start, ev_stop);
     pl->cur = slot;
     pl->last_resident = rr == 0;
     if (rr >= 0) return rr;
+    const int rc = fused_run_steps(pl, slot, call, steps, nsteps, s, ev_start);
+    if (ev_stop && hipEventRecord(ev_stop, s) != hipSuccess) return 1;
+    return rc;
+}
+
+// the single-step kernels of a call (one launch per step, or the cached hipGraph of them), behind ev_start when given
+static int fused_run_steps(FusedPlan *pl, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s, hipEvent_t ev_start)
+{
+    if (ev_start && hipEventRecord(ev_start, s) != hipSuccess) return 1;
     if (!pl->use_graph || pl->stamps_path) {
         for (int i = 0; i < nsteps; ++i) fused_launch(pl, slot, call, i, steps[i], s);
         return hipGetLastError() == hipSuccess ? 0 : 1;
