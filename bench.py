@@ -279,7 +279,12 @@ def main():
     import waves_jl_amd as w
     from waves_jl_amd import dist as wd
 
-    rank, local_rank, world = wd.init()
+    # (a rehearsal with several ranks on ONE GPU cannot use RCCL -- it refuses two ranks on a device -- and takes gloo)
+    shared = (os.environ.get("WAVES_AMD_ALLOW_SHARED_GPU") and
+              0 < torch.cuda.device_count() < int(os.environ.get("WORLD_SIZE", "1")))
+    if shared:  # no rank has the device to itself: the resident kernel (all its tiles co-resident) is nobody's to use
+        os.environ["WAVES_AMD_FUSED_RESIDENT"] = "0"
+    rank, local_rank, world = wd.init("gloo" if shared else None)
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
