@@ -85,8 +85,9 @@ def test_signal_continuity_and_frames_across_actions():
     assert env.time_step == 0 and not env.wave.any()
 
 
-def test_pml_decay_2048():
-    """after the source is switched off the PML drains the domain: energy strictly decreases late in the run"""
+def test_pml_decay_512_2000_steps():
+    """after the source is switched off the PML drains the domain: 2 % of the initial energy is left after 2000 steps
+    (512^2: the 2048^2 width sweep of config 4 is tests/test_gpu_round2.py::test_config4_2048_500_steps_width_sweep_properties)"""
     dim, ctx = ctx_for(512, "auto", 2.0)
     ic = wo.build_normal(wo.build_grid(dim), np.array([[0.0, 0.0]]), np.array([0.6]), np.array([1.0]))
     u0 = np.zeros((512, 512, 12), f32, order="F")
