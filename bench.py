@@ -442,7 +442,7 @@ def main():
         if world == 1 and args.side_configs and ngrid == N_GRID and E == 1 and not args.stub_env:
             for en in envs:  # (a context takes the resident path only when it has the device to itself)
                 en.ctx.close()
-            out["configs"] = {"config4_2048_w2": side_config(w, ds, dev, args.impl, 2048, 2.0, 3, traffic_tab),
+            out["configs"] = {"config4_2048_w2": side_config(w, ds, dev, args.impl, 2048, 2.0, 6, traffic_tab),
                               "config1_size_256": side_config(w, ds, dev, args.impl, 256, 2.0, 10, traffic_tab)}
         if world == 1 and args.batch_envs > 1 and E == 1 and not args.stub_env:
             out["batched"] = batched_envs(w, dim, ds, dev, args.impl, args.batch_envs, args.pml_width)
