@@ -155,6 +155,47 @@ def spawn_ranks(n: int) -> int:
     return rc
 
 
+def rollout_config5(w, dim, ds, dev, impl, pml_width, episodes=3, actions=20):
+    """BASELINE config 5 on one GPU: rollouts of `actions` x 100 steps with RandomDesignPolicy, every rollout ONE device call
+    (WaveEnv.steps_begin / wv_set_design_sequence: the policy does not read the wave state between actions), two calls in
+    flight.  Reported next to the headline, never as `value`."""
+    import torch
+    env, policy = make_env(w, dim, ds, dev, impl, pml_width, actions * (episodes + 2), 4242)
+    w.rollout_batched(env, policy, actions)   # warm-up: allocations, code, the step table of this shape
+    gc.collect()
+    gc.freeze()
+    torch.cuda.synchronize()
+    kern_ms, launches = 0.0, 0
+    t0 = time.perf_counter()
+    env.steps_begin([policy(env) for _ in range(actions)])
+    for _ in range(episodes - 1):
+        env.steps_begin([policy(env) for _ in range(actions)])
+        env.steps_end()
+        kern_ms += env.ctx.timing()["step_kernel_ms"]
+        launches += 1
+    env.steps_end()
+    kern_ms += env.ctx.timing()["step_kernel_ms"]
+    launches += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tim = env.ctx.timing()
+    n = len(dim.x)
+    steps = actions * STEPS_PER_ACTION
+    avg_ms = kern_ms / launches
+    resident = bool(tim["resident"])
+    out = {"workload": f"{episodes} rollouts of {actions} actions x {STEPS_PER_ACTION} steps, RandomDesignPolicy, one device call per "
+                       "rollout, two calls in flight", "kernel": "k_steps_resident" if resident else "k_step_fused",
+           "value": round(episodes * steps * n * n / dt / 1e6, 2), "unit": "Mcell-updates/s",
+           "ms_per_action": round(dt / (episodes * actions) * 1e3, 4),
+           "whole_job_frac": round(B_ALG * episodes * steps * n * n / dt / (HBM_PEAK_GBS * 1e9), 4),
+           "signal_checksum": float(np.sum(env.signal))}
+    if resident:
+        out.update({"avg_kernel_us": round(avg_ms * 1e3, 3), "steps_per_launch": steps,
+                    "frac": round(B_ALG * n * n * steps / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+    env.ctx.close()
+    return out
+
+
 def make_env(w, dim, ds, dev, impl, pml_width, actions, seed, **kw):
     src = w.RandomPosGaussianSource(w.build_grid(dim), [[-10.0, -10.0]], [[-10.0, 10.0]], [0.3], [1.0], 1000.0,
                                     rng=np.random.default_rng(2 + seed))
@@ -444,6 +485,8 @@ def main():
                 en.ctx.close()
             out["configs"] = {"config4_2048_w2": side_config(w, ds, dev, args.impl, 2048, 2.0, 6, traffic_tab),
                               "config1_size_256": side_config(w, ds, dev, args.impl, 256, 2.0, 10, traffic_tab)}
+        if world == 1 and args.side_configs and ngrid == N_GRID and E == 1 and not args.stub_env:
+            out["rollout_config5"] = rollout_config5(w, dim, ds, dev, args.impl, args.pml_width)
         if world == 1 and args.batch_envs > 1 and E == 1 and not args.stub_env:
             out["batched"] = batched_envs(w, dim, ds, dev, args.impl, args.batch_envs, args.pml_width)
         if world == 1 and args.cpu_steps > 0 and not args.stub_env:

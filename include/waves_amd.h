@@ -133,6 +133,20 @@ int wv_observation(wv_ctx *ctx, int rx, int ry, float *out /* rx*ry*4 */);
 int wv_set_design(wv_ctx *ctx, int M, const float *pos_initial, const float *r_initial, const float *c_initial,
                   const float *pos_final, const float *r_final, const float *c_final, float ti, float tf);
 
+/* n actions integrated by ONE call: the reference's loop `for a in actions; env(a); end` (src/data.jl:22-27 around
+ * src/env.jl:91-121) for a policy that does not read the wave state between actions (RandomDesignPolicy,
+ * src/env.jl:151-157).  designs holds n_actions + 1 designs of M cylinders as {px, py, r, c} per cylinder -- design k
+ * is the one in force before action k, design k + 1 the one it moves to -- and ti_tf the (ti, tf) of every action's
+ * DesignInterpolator (src/env.jl:95-98).  The sequence describes the NEXT wv_integrate / wv_integrate_begin call and only
+ * that one: its nsteps must be n_actions * steps_per_action, its tspan holds every action's own tspan in a row
+ * (n_actions x (steps_per_action + 1) values: step s of action k starts at tspan[k * (steps_per_action + 1) + s]), its
+ * signal has n_actions * steps_per_action + 1 rows (row k * steps_per_action is the last row of action k - 1 and the first of
+ * action k), capture_frames keeps the three frames of the LAST action, trajectories are not available.  Afterwards the
+ * context's design is the last action's interpolator.  One launch instead of n: the start-up of a launch and the gap
+ * between two launches (together ~8 % of a 100-step action at 700^2) are paid once. */
+int wv_set_design_sequence(wv_ctx *ctx, int n_actions, int steps_per_action, int M, const float *designs /* (n_actions+1)*M*4 */,
+                           const float *ti_tf /* n_actions*2 */);
+
 /* The closures evaluated at one time (for tests / drop-in of speed() and the source call). */
 int wv_speed_field(wv_ctx *ctx, float t, float *out /* nx*ny */);   /* src/designs.jl:110-116 via :287-292 */
 int wv_source_field(wv_ctx *ctx, float t, float *out /* nx*ny */);  /* src/sources.jl:67-69 */

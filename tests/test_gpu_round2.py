@@ -220,6 +220,43 @@ def test_two_actions_in_flight_equal_one_at_a_time(monkeypatch, n, resident):
     env2.ctx.close()
 
 
+@pytest.mark.parametrize("n,resident,per", [(700, True, None), (300, True, 2), (300, False, None)])
+def test_action_sequence_in_one_call_equals_one_call_per_action(monkeypatch, n, resident, per):
+    """w.rollout_batched / WaveEnv.steps_begin (wv_set_design_sequence): several actions of a state-independent policy in
+    ONE device call.  Every action's signal, the final env.wave and the bookkeeping must be bit-identical to the plain
+    `env(policy(env))` loop (src/data.jl:22-27)."""
+    gc.collect()
+    monkeypatch.setenv("WAVES_AMD_FUSED_RESIDENT", "1" if resident else "0")
+    steps, actions = 40, 5
+    env, pol = _env(n, steps, actions, 91)
+    ref = []
+    while not env.is_terminated():
+        env(pol(env))
+        ref.append(env.signal)
+    wave_ref, design_ref, ts_ref = env.wave, env.design.stacked().r.copy(), env.time_step
+    env.ctx.close()
+    gc.collect()
+    env, pol = _env(n, steps, actions, 91)
+    got = w.rollout_batched(env, pol, actions, per_launch=per)
+    assert env.ctx.timing()["resident"] is resident
+    assert env.is_terminated() and len(got) == actions and env.time_step == ts_ref
+    for a, b in zip(ref, got):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    assert np.array_equal(env.signal, ref[-1])
+    assert np.array_equal(env.wave, wave_ref) and np.array_equal(env.design.stacked().r, design_ref)
+    # the context is back to one design: a plain action after the sequence continues the rollout
+    env.actions += 1
+    env(pol(env))
+    assert np.all(np.isfinite(env.signal)) and env.signal.shape == (steps + 1, 3)
+    # a sequence whose length does not match the call is refused and consumed
+    c = env.design.stacked()
+    env.ctx.set_design_sequence([(c.pos, c.r, c.c)] * 3, [(0.0, 1.0)] * 2, steps)
+    with pytest.raises(w.WavesAmdError) as ei:
+        env.ctx.integrate_begin(env.build_tspan(), capture_frames=True)
+    assert ei.value.status == w._ffi.WV_ERR_INVALID
+    env.ctx.close()
+
+
 def test_state_written_through_the_raw_device_pointer_is_looked_at_again():
     """wv_device_frames hands out env.wave's device pointer; until wv_release_device_frames every integrate re-derives
     what it otherwise caches about the state (field-set precondition, initial energies)."""

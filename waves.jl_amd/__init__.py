@@ -14,7 +14,7 @@ from .designs import (AIR, ALUMINIUM, BRASS, COPPER, WATER, AdjustablePositionSc
 from .dims import TwoDim, build_dirichlet, build_grid, build_wave, get_dx, get_dy
 from .dynamics import AcousticDynamics, Integrator, UniformSpeed, build_tspan, runge_kutta
 from .env import (FRAMESKIP, RandomDesignPolicy, WaveEnv, WaveEnvState, action_space, is_terminated, reset, reward,
-                  rollout_pipelined, state, step_all)
+                  rollout_batched, rollout_pipelined, state, step_all)
 from .latent import LatentIntegrator, LatentSource, LinearInterpolation, OneDim, compute_latent_energy
 from .sources import NoSource, RandomPosGaussianSource, Source
 

@@ -95,6 +95,7 @@ def lib():
     _sig(L, "wv_get_source_shape", [ctx, _fp])
     _sig(L, "wv_observation", [ctx, C.c_int, C.c_int, _fp])
     _sig(L, "wv_set_design", [ctx, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_float])
+    _sig(L, "wv_set_design_sequence", [ctx, C.c_int, C.c_int, C.c_int, _fp, _fp])
     _sig(L, "wv_speed_field", [ctx, C.c_float, _fp])
     _sig(L, "wv_source_field", [ctx, C.c_float, _fp])
     _sig(L, "wv_gradient", [ctx, C.c_int, _fp, _fp])
@@ -255,6 +256,26 @@ class Context:
         for a in arrs:
             assert a.shape[0] == M
         self._ck(self._L.wv_set_design(self._h, M, *[fptr(a) for a in arrs], float(ti), float(tf)))
+
+    def set_design_sequence(self, designs, ti_tf, steps_per_action):
+        """The designs of n actions that the NEXT integrate call runs in one launch: designs = n + 1 tuples
+        (pos (M,2), r (M,), c (M,)) -- design k in force before action k, k + 1 after it --, ti_tf = n pairs (ti, tf)."""
+        rows = [np.concatenate([np.asarray(pos, np.float32).reshape(-1, 2), np.asarray(r, np.float32).reshape(-1, 1),
+                                np.asarray(c, np.float32).reshape(-1, 1)], axis=1) for pos, r, c in designs]
+        d = np.ascontiguousarray(np.stack(rows), np.float32)          # (n + 1, M, 4): px, py, r, c
+        tt = np.ascontiguousarray(ti_tf, np.float32).reshape(-1, 2)
+        assert d.shape[0] == tt.shape[0] + 1
+        self._ck(self._L.wv_set_design_sequence(self._h, tt.shape[0], int(steps_per_action), d.shape[1], fptr(d), fptr(tt)))
+
+    def integrate_sequence_begin(self, tspans, *, capture_frames=True, want_signal=True):
+        """tspans: (n, steps + 1) -- every action's own tspan; after set_design_sequence.  Ended by integrate_end, whose
+        signal has n * steps + 1 rows."""
+        ts = np.ascontiguousarray(tspans, np.float32)
+        n, per = ts.shape[0], ts.shape[1] - 1
+        self._ck(self._L.wv_integrate_begin(self._h, fptr(ts), n * per, int(bool(capture_frames)), int(bool(want_signal)), 0))
+        if not hasattr(self, "_pend"):
+            self._pend = []
+        self._pend.append((n * per, bool(want_signal), False))
 
     def observation(self, rx, ry):
         """state(env)'s x: (rx, ry, 4) = imresize(cat(u_tot frames, source shape), (rx, ry)), resized on the device."""

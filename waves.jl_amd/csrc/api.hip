@@ -40,6 +40,10 @@ struct wv_ctx {
     int M = 0;
     std::vector<float> d0, d1;
     float ti = 0.0f, tf = 0.0f;
+    // wv_set_design_sequence: the designs of n actions integrated by the NEXT call (consumed by it)
+    int seq_n = 0, seq_steps = 0;
+    std::vector<float> seq_d;   // (seq_n + 1) x M x {px, py, r, c}
+    std::vector<float> seq_t;   // seq_n x {ti, tf}
 
     Cyl *d_cyl = nullptr;      // one stage time: wv_speed_field / wv_rhs
     size_t cyl_cap = 0;
@@ -170,17 +174,17 @@ static float mean_diff(const std::vector<float> &x)
 
 // DesignInterpolator call, src/designs.jl:287-292 with the algebra of :47-53: per scalar component
 //   v_i + ((v_f + (-1f0*v_i)) * (1f0/Dt)) * (clamp(t, ti, tf) - ti)
-static void design_at(const wv_ctx *c, float t, Cyl *out)
+static void design_at(int M, const float *d0, const float *d1, float ti, float tf, float t, Cyl *out)
 {
-    float dt = c->tf - c->ti;
+    float dt = tf - ti;
     dt = dt > 0.0f ? dt : 1.0f;
     const float inv_dt = 1.0f / dt;
-    const float tc = t < c->ti ? c->ti : (t > c->tf ? c->tf : t);
-    const float tau = tc - c->ti;
-    for (int m = 0; m < c->M; ++m) {
+    const float tc = t < ti ? ti : (t > tf ? tf : t);
+    const float tau = tc - ti;
+    for (int m = 0; m < M; ++m) {
         float v[4];
         for (int k = 0; k < 4; ++k) {
-            const float vi = c->d0[4 * m + k], vf = c->d1[4 * m + k];
+            const float vi = d0[4 * m + k], vf = d1[4 * m + k];
             const float dy = vf + (-1.0f * vi);
             v[k] = vi + (dy * inv_dt) * tau;
         }
@@ -190,6 +194,7 @@ static void design_at(const wv_ctx *c, float t, Cyl *out)
         out[m].c = v[3];
     }
 }
+static void design_at(const wv_ctx *c, float t, Cyl *out) { design_at(c->M, c->d0.data(), c->d1.data(), c->ti, c->tf, t, out); }
 
 // sin.(2.0f0 * pi * t * freq): ((2f0*pi)*t)*freq in fp32, accurately rounded sin.  src/sources.jl:21-22,67-69
 static float source_factor(float t, float freq)
@@ -549,7 +554,8 @@ int wv_set_design(wv_ctx *c, int M, const float *pos_i, const float *r_i, const 
     CHECK_CTX(c);
     if (M < 0 || M > 4096) return fail(c, WV_ERR_INVALID, "wv_set_design: M out of range [0, 4096]");
     if (M > 0 && (!pos_i || !r_i || !c_i || !pos_f || !r_f || !c_f)) return fail(c, WV_ERR_INVALID, "wv_set_design: NULL array");
-        c->M = M;
+    c->M = M;
+    c->seq_n = 0;  // (a plain design replaces a pending sequence)
     c->ti = ti;
     c->tf = tf;
     c->d0.resize(4 * (size_t)M);
@@ -564,6 +570,26 @@ int wv_set_design(wv_ctx *c, int M, const float *pos_i, const float *r_i, const 
         c->d1[4 * m + 2] = r_f[m];
         c->d1[4 * m + 3] = c_f[m];
     }
+    return WV_OK;
+}
+
+int wv_set_design_sequence(wv_ctx *c, int n_actions, int steps_per_action, int M, const float *designs, const float *ti_tf)
+{
+    CHECK_CTX(c);
+    if (n_actions < 1 || steps_per_action < 1) return fail(c, WV_ERR_INVALID, "wv_set_design_sequence: n_actions and steps_per_action must be >= 1");
+    if (M < 1 || M > 4096) return fail(c, WV_ERR_INVALID, "wv_set_design_sequence: M out of range [1, 4096]");
+    if (!designs || !ti_tf) return fail(c, WV_ERR_INVALID, "wv_set_design_sequence: NULL array");
+    if ((long long)n_actions * steps_per_action > (1 << 20)) return fail(c, WV_ERR_INVALID, "wv_set_design_sequence: more than 2^20 steps");
+    c->M = M;
+    c->seq_n = n_actions;
+    c->seq_steps = steps_per_action;
+    c->seq_d.assign(designs, designs + (size_t)(n_actions + 1) * M * 4);
+    c->seq_t.assign(ti_tf, ti_tf + 2 * (size_t)n_actions);
+    // what a later call without a sequence sees: the last action's interpolator (as after n wv_set_design calls)
+    c->d0.assign(c->seq_d.end() - 2 * (size_t)M * 4, c->seq_d.end() - (size_t)M * 4);
+    c->d1.assign(c->seq_d.end() - (size_t)M * 4, c->seq_d.end());
+    c->ti = c->seq_t[2 * (size_t)(n_actions - 1)];
+    c->tf = c->seq_t[2 * (size_t)(n_actions - 1) + 1];
     return WV_OK;
 }
 
@@ -689,6 +715,11 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
                                          "when neither call returns trajectories through the device buffer and profiling is off)");
     }
     if (!tspan || nsteps < 1) return fail(c, WV_ERR_INVALID, "wv_integrate: tspan NULL or nsteps < 1");
+    const int seq_n = c->seq_n, sps = c->seq_steps;  // a design sequence describes this call (and only this one)
+    c->seq_n = 0;
+    if (seq_n > 0 && (long long)seq_n * sps != nsteps)
+        return fail(c, WV_ERR_INVALID, "wv_integrate: nsteps must be n_actions * steps_per_action of wv_set_design_sequence");
+    if (seq_n > 0 && want_fields) return fail(c, WV_ERR_INVALID, "wv_integrate: a design sequence returns no trajectories");
     if (capture && nsteps < 2 * WV_FRAMESKIP)
         return fail(c, WV_ERR_INVALID,
                     "wv_integrate: capture_frames needs nsteps >= 20 (sol[:, :, :, end-20:10:end], src/env.jl:116)");
@@ -716,17 +747,24 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     float t_lo = INFINITY, t_hi = -INFINITY;
     bool t_ok = true;
     for (int s = 0; s < nsteps; ++s) {
-        const float t = tspan[s];
+        // (a sequence: every action brings its own tspan of sps + 1 entries and its own interpolator)
+        const int act = seq_n > 0 ? s / sps : 0;
+        const float t = seq_n > 0 ? tspan[(size_t)act * (sps + 1) + (s - act * sps)] : tspan[s];
         const float tq[3] = {t, t + hdt, t + dt};
         for (int k = 0; k < 3; ++k) {
             q.h_sfac[3 * s + k] = c->has_source ? source_factor(tq[k], c->freq) : 0.0f;
-            if (M > 0) design_at(c, tq[k], q.h_cyl + (size_t)(3 * s + k) * M);
+            if (M > 0 && seq_n > 0)
+                design_at(M, c->seq_d.data() + (size_t)act * M * 4, c->seq_d.data() + (size_t)(act + 1) * M * 4, c->seq_t[2 * (size_t)act],
+                          c->seq_t[2 * (size_t)act + 1], tq[k], q.h_cyl + (size_t)(3 * s + k) * M);
+            else if (M > 0)
+                design_at(c, tq[k], q.h_cyl + (size_t)(3 * s + k) * M);
             t_ok = t_ok && isfinite(tq[k]);
             if (tq[k] < t_lo) { t_lo = tq[k]; row_lo = 3 * s + k; }
             if (tq[k] > t_hi) { t_hi = tq[k]; row_hi = 3 * s + k; }
         }
     }
     if (!t_ok) row_lo = row_hi = -1;  // (a NaN time: let the culling look at every row)
+    if (seq_n > 0) row_lo = row_hi = -1;  // (a sequence is not ONE monotone interpolation: every row)
     g_hostprof.lap(0);
     if (M > 0) HIPCHK(c, hipMemcpyAsync(q.d_cyl, q.h_cyl, ncyl * sizeof(Cyl), hipMemcpyHostToDevice, up));
     HIPCHK(c, hipMemcpyAsync(q.d_sfac, q.h_sfac, nsf * sizeof(float), hipMemcpyHostToDevice, up));

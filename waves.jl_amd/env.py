@@ -106,6 +106,43 @@ class WaveEnv:
         self.design = next_design
         self.time_step += self.integration_steps
 
+    def steps_begin(self, actions):
+        """`for a in actions; env(a); end` (src/data.jl:22-27) enqueued as ONE device call: valid when the actions do not
+        depend on the wave state in between (RandomDesignPolicy, src/env.jl:151-157).  The launch start-up and the gap
+        between two launches are paid once for all of them (wv_set_design_sequence).  env.design / env.time_step advance
+        here as in step_begin; steps_end returns every action's signal; env.wave holds the frames of the LAST action."""
+        if self.return_fields:
+            raise ValueError("steps_begin: trajectories are per action -- use step_begin / step_end")
+        if self.integration_steps < 2 * FRAMESKIP:
+            raise IndexError("BoundsError: sol[:, :, :, end-20:10:end] needs integration_steps >= 20 (src/env.jl:116)")
+        tspans, interps, designs = [], [], [self.design]
+        for action in actions:
+            tspan = self.build_tspan()
+            current_design = self.design
+            next_design = self.design_space(current_design, action)
+            interps.append(DesignInterpolator(current_design, next_design, self.time(), tspan[-1]))
+            tspans.append(tspan)
+            designs.append(next_design)
+            self.design = next_design
+            self.time_step += self.integration_steps
+        stk = [d.stacked() for d in designs]
+        if stk[0] is None:
+            raise ValueError("steps_begin: NoDesign has nothing to move -- use step_begin")
+        self.ctx.set_design_sequence([(c.pos, c.r, c.c) for c in stk], [(i.ti, i.tf) for i in interps], self.integration_steps)
+        self.ctx.integrate_sequence_begin(np.stack(tspans), capture_frames=True, want_signal=True)
+        if not hasattr(self, "_pending") or self._pending is None:
+            self._pending = []
+        self._pending.append((tspans, interps))
+
+    def steps_end(self):
+        """Second half of steps_begin: the list of every action's env.signal (src/env.jl:114); env.signal is the last."""
+        tspans, interps = self._pending.pop(0)
+        sig, _, _ = self.ctx.integrate_end()
+        n = self.integration_steps
+        sigs = [sig[k * n:(k + 1) * n + 1].copy() for k in range(len(tspans))]
+        self.signal = sigs[-1]
+        return sigs
+
     def step_end(self):
         """Second half of env(action): wait for the device work of the oldest action in flight (src/env.jl:114,120)."""
         tspan, interp = self._pending.pop(0)
@@ -142,6 +179,26 @@ def rollout_pipelined(env, policy, n_actions):
     if n_actions > 0:
         env.step_end()
         sigs.append(env.signal)
+    return sigs
+
+
+def rollout_batched(env, policy, n_actions, per_launch=None):
+    """The same loop with `per_launch` actions per device call (default: all of them in one), two calls in flight.  For
+    policies that do not look at the wave state; returns the list of env.signal, action by action."""
+    per = n_actions if per_launch is None else max(1, int(per_launch))
+    sigs, inflight = [], 0
+    k = 0
+    while k < n_actions:
+        m = min(per, n_actions - k)
+        env.steps_begin([policy(env) for _ in range(m)])
+        inflight += 1
+        k += m
+        if inflight == 2:
+            sigs += env.steps_end()
+            inflight -= 1
+    while inflight:
+        sigs += env.steps_end()
+        inflight -= 1
     return sigs
 
 
