@@ -143,3 +143,69 @@ def test_episode_file_round_trip_without_pickle(tmp_path):
     bare = _toy_episode(A=2, n=5, with_states=False)
     bare.save(p)
     assert w.Episode.load(p).s == [] and len(w.Episode.load(p)) == 2
+
+
+class _RecordingCtx:
+    """Stands in for the device context: records what WaveEnv hands to the ABI."""
+
+    def __init__(self):
+        self.calls, self._rows = [], []
+
+    def set_design(self, initial, final, ti, tf):
+        self.calls.append(("design", initial, final, np.float32(ti), np.float32(tf)))
+
+    def integrate_begin(self, tspan, **kw):
+        self.calls.append(("begin", np.array(tspan, np.float32)))
+        self._rows.append(len(tspan))
+
+    def set_design_sequence(self, designs, ti_tf, steps_per_action):
+        self.calls.append(("sequence", designs, np.array(ti_tf, np.float32), steps_per_action))
+
+    def integrate_sequence_begin(self, tspans, **kw):
+        ts = np.array(tspans, np.float32)
+        self.calls.append(("sequence_begin", ts))
+        self._rows.append(ts.shape[0] * (ts.shape[1] - 1) + 1)
+
+    def integrate_end(self):
+        n = self._rows.pop(0)
+        return np.arange(3 * n, dtype=np.float32).reshape(n, 3), None, None
+
+
+def _bare_env(seed, steps=30, actions=4):
+    env = object.__new__(w.WaveEnv)   # (the constructor opens a device context: not on a CPU-only machine)
+    env.rng = np.random.default_rng(seed)
+    env.design_space = w.build_triple_ring_design_space()
+    env.design = w.rand(env.design_space, env.rng)
+    env.ctx = _RecordingCtx()
+    env.signal = np.zeros(steps + 1, np.float32)
+    env.time_step, env.dt, env.integration_steps, env.actions = 0, np.float32(1e-5), steps, actions
+    env.action_speed, env.return_fields, env._pending = np.float32(250.0), False, None
+    return env, w.RandomDesignPolicy(env.action_space(), np.random.default_rng(seed + 1))
+
+
+def test_action_sequence_hands_the_abi_what_the_per_action_loop_does():
+    """WaveEnv.steps_begin (one device call for n actions, wv_set_design_sequence) against n x step_begin: the same designs,
+    interpolation intervals and tspans reach the ABI, the bookkeeping ends in the same place, steps_end cuts the
+    (n*steps + 1)-row trace into the n overlapping (steps + 1)-row signals."""
+    n, steps = 4, 30
+    a, pa = _bare_env(5, steps, n)
+    for _ in range(n):
+        a.step_begin(pa(a))
+    b, pb = _bare_env(5, steps, n)
+    sigs = w.rollout_batched(b, pb, n)
+    designs_a = [c for c in a.ctx.calls if c[0] == "design"]
+    begins_a = [c for c in a.ctx.calls if c[0] == "begin"]
+    (_, designs_b, titf_b, sps), (_, tspans_b) = b.ctx.calls
+    assert sps == steps and len(designs_b) == n + 1 and tspans_b.shape == (n, steps + 1)
+    for k in range(n):
+        _, ini, fin, ti, tf = designs_a[k]
+        for got, want in ((designs_b[k], ini), (designs_b[k + 1], fin)):
+            assert all(np.array_equal(g, x) for g, x in zip(got, want))
+        assert titf_b[k, 0] == ti and titf_b[k, 1] == tf
+        assert np.array_equal(tspans_b[k], begins_a[k][1])
+    assert a.time_step == b.time_step == n * steps
+    assert np.array_equal(a.design.stacked().r, b.design.stacked().r)
+    assert len(sigs) == n and all(s.shape == (steps + 1, 3) for s in sigs)
+    for k in range(n):   # rows k*steps .. (k+1)*steps of the whole trace; neighbours share their boundary row
+        assert sigs[k][0, 0] == 3 * k * steps and sigs[k][-1, 0] == 3 * (k + 1) * steps
+    assert np.array_equal(b.signal, sigs[-1])
