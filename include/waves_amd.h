@@ -141,11 +141,19 @@ int wv_set_design(wv_ctx *ctx, int M, const float *pos_initial, const float *r_i
  * that one: its nsteps must be n_actions * steps_per_action, its tspan holds every action's own tspan in a row
  * (n_actions x (steps_per_action + 1) values: step s of action k starts at tspan[k * (steps_per_action + 1) + s]), its
  * signal has n_actions * steps_per_action + 1 rows (row k * steps_per_action is the last row of action k - 1 and the first of
- * action k), capture_frames keeps the three frames of the LAST action, trajectories are not available.  Afterwards the
+ * action k), capture_frames == 1 keeps the three frames of the LAST action (env.wave), capture_frames == 2 those of
+ * every action (steps_per_action > 20; such a call is not overlapped with another one; wv_observation_action /
+ * wv_get_frames_action read them until the next integrate call), trajectories are not available.  Afterwards the
  * context's design is the last action's interpolator.  One launch instead of n: the start-up of a launch and the gap
  * between two launches (together ~8 % of a 100-step action at 700^2) are paid once. */
 int wv_set_design_sequence(wv_ctx *ctx, int n_actions, int steps_per_action, int M, const float *designs /* (n_actions+1)*M*4 */,
                            const float *ti_tf /* n_actions*2 */);
+
+/* env.wave / state(env) as they were after action `action` (0-based) of the last wv_integrate call that ran a design
+ * sequence with capture_frames == 2: what `s = state(env)` in front of action + 1 sees in the reference's rollout loop
+ * (src/data.jl:23, src/env.jl:132-137).  The last action's are wv_get_frames / wv_observation themselves. */
+int wv_observation_action(wv_ctx *ctx, int action, int rx, int ry, float *out /* rx*ry*4 */);
+int wv_get_frames_action(wv_ctx *ctx, int action, float *wave /* 12*nx*ny*3 */);
 
 /* The closures evaluated at one time (for tests / drop-in of speed() and the source call). */
 int wv_speed_field(wv_ctx *ctx, float t, float *out /* nx*ny */);   /* src/designs.jl:110-116 via :287-292 */

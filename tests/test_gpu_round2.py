@@ -257,6 +257,68 @@ def test_action_sequence_in_one_call_equals_one_call_per_action(monkeypatch, n, 
     env.ctx.close()
 
 
+@pytest.mark.parametrize("resident", [True, False])
+def test_action_sequence_keeps_the_frames_of_every_action(monkeypatch, resident):
+    """steps_begin(..., keep_frames=True) (capture_frames == 2): env.wave and state(env) after EVERY action of the one
+    device call, bit-identical to what the plain `env(policy(env))` loop sees between its actions (src/data.jl:22-27)."""
+    gc.collect()
+    monkeypatch.setenv("WAVES_AMD_FUSED_RESIDENT", "1" if resident else "0")
+    n, steps, actions = 300, 40, 4
+    env, pol = _env(n, steps, actions, 123)
+    waves, obs, designs, tspans, sigs = [], [], [], [], []
+    while not env.is_terminated():
+        env(pol(env))
+        waves.append(env.wave)
+        st = env.state()
+        obs.append(st.wave); designs.append(st.design.stacked().r.copy()); tspans.append(np.array(st.tspan))
+        sigs.append(env.signal)
+    env.ctx.close()
+    gc.collect()
+    env, pol = _env(n, steps, actions, 123)
+    env.steps_begin([pol(env) for _ in range(actions)], keep_frames=True)
+    with pytest.raises(w.WavesAmdError):   # not overlapped with another call
+        env.ctx.integrate_begin(env.build_tspan(), capture_frames=True)
+    got = env.steps_end()
+    assert env.ctx.timing()["resident"] is resident
+    for k in range(actions):
+        assert np.array_equal(got[k], sigs[k])
+        assert np.array_equal(env.ctx.get_frames_action(k), waves[k])
+        st = env.state_after(k)
+        assert np.array_equal(st.wave, obs[k]) and np.array_equal(st.design.stacked().r, designs[k])
+        assert np.array_equal(st.tspan, tspans[k])
+    assert np.array_equal(env.wave, waves[-1])
+    with pytest.raises(w.WavesAmdError):
+        env.ctx.get_frames_action(actions)
+    # any later integrate call ends the validity of the kept frames
+    env.actions += 1
+    env(pol(env))
+    with pytest.raises(w.WavesAmdError):
+        env.ctx.observation_action(0, 32, 32)
+    env.ctx.close()
+
+
+def test_generate_episode_in_one_launch_equals_the_plain_loop():
+    """generate_episode(..., with_states=True, per_launch=n): the episode of src/data.jl:12-33 (states in front of every
+    action, actions, tspans, signals) from ONE device call per n actions, equal to the plain loop's."""
+    gc.collect()
+    n, steps, actions = 300, 40, 5
+
+    def episode(**kw):
+        env, pol = _env(n, steps, actions, 321)
+        ep = w.generate_episode(pol, env, reset=False, with_states=True, **kw)
+        env.ctx.close()
+        gc.collect()
+        return ep
+
+    ref, got = episode(in_flight=1), episode(per_launch=3)
+    assert len(ref) == len(got) == actions and len(got.s) == actions
+    for k in range(actions):
+        assert np.array_equal(ref.s[k].wave, got.s[k].wave) and np.array_equal(ref.s[k].tspan, got.s[k].tspan)
+        assert np.array_equal(ref.s[k].design.stacked().r, got.s[k].design.stacked().r)
+        assert np.array_equal(ref.a[k].stacked().r, got.a[k].stacked().r)
+        assert np.array_equal(ref.t[k], got.t[k]) and np.array_equal(ref.y[k], got.y[k])
+
+
 def test_state_written_through_the_raw_device_pointer_is_looked_at_again():
     """wv_device_frames hands out env.wave's device pointer; until wv_release_device_frames every integrate re-derives
     what it otherwise caches about the state (field-set precondition, initial energies)."""

@@ -96,6 +96,8 @@ def lib():
     _sig(L, "wv_observation", [ctx, C.c_int, C.c_int, _fp])
     _sig(L, "wv_set_design", [ctx, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_float])
     _sig(L, "wv_set_design_sequence", [ctx, C.c_int, C.c_int, C.c_int, _fp, _fp])
+    _sig(L, "wv_observation_action", [ctx, C.c_int, C.c_int, C.c_int, _fp])
+    _sig(L, "wv_get_frames_action", [ctx, C.c_int, _fp])
     _sig(L, "wv_speed_field", [ctx, C.c_float, _fp])
     _sig(L, "wv_source_field", [ctx, C.c_float, _fp])
     _sig(L, "wv_gradient", [ctx, C.c_int, _fp, _fp])
@@ -269,10 +271,12 @@ class Context:
 
     def integrate_sequence_begin(self, tspans, *, capture_frames=True, want_signal=True):
         """tspans: (n, steps + 1) -- every action's own tspan; after set_design_sequence.  Ended by integrate_end, whose
-        signal has n * steps + 1 rows."""
+        signal has n * steps + 1 rows.  capture_frames="all": the frames of every action are kept on the device
+        (observation_action / get_frames_action)."""
         ts = np.ascontiguousarray(tspans, np.float32)
         n, per = ts.shape[0], ts.shape[1] - 1
-        self._ck(self._L.wv_integrate_begin(self._h, fptr(ts), n * per, int(bool(capture_frames)), int(bool(want_signal)), 0))
+        cap = 2 if capture_frames == "all" else int(bool(capture_frames))
+        self._ck(self._L.wv_integrate_begin(self._h, fptr(ts), n * per, cap, int(bool(want_signal)), 0))
         if not hasattr(self, "_pend"):
             self._pend = []
         self._pend.append((n * per, bool(want_signal), False))
@@ -282,6 +286,18 @@ class Context:
         o = np.empty((int(rx), int(ry), 4), np.float32, order="F")
         self._ck(self._L.wv_observation(self._h, int(rx), int(ry), fptr(o)))
         return o
+
+    def observation_action(self, action, rx, ry):
+        """observation() as it was after action `action` of the last sequence call begun with capture_frames="all"."""
+        o = np.empty((int(rx), int(ry), 4), np.float32, order="F")
+        self._ck(self._L.wv_observation_action(self._h, int(action), int(rx), int(ry), fptr(o)))
+        return o
+
+    def get_frames_action(self, action):
+        """get_frames() as it was after action `action` of the last sequence call begun with capture_frames="all"."""
+        wv = np.empty((self.nx, self.ny, 12, 3), np.float32, order="F")
+        self._ck(self._L.wv_get_frames_action(self._h, int(action), fptr(wv)))
+        return wv
 
     def speed_field(self, t):
         o = np.empty((self.nx, self.ny), np.float32, order="F")

@@ -55,6 +55,11 @@ struct wv_ctx {
     size_t small_cap = 0;
     float *d_obs = nullptr;    // wv_observation output
     size_t obs_cap = 0;
+    // capture_frames == 2 of a design sequence: the three frames of every action but the last (those are env.wave itself)
+    float *d_seq_frames = nullptr;
+    size_t seq_frames_cap = 0;
+    int seq_frames_actions = 0;     // actions of the last such call (0: none): wv_observation_action / wv_get_frames_action
+    bool seq_frames_clean = false;  // the buffer holds zeros wherever a reduced-field-set tile does not write
     std::vector<FusedStep> fsteps;
     bool counted = false;  // this ctx is included in g_live_ctx
     int elast_generation = -1;
@@ -79,6 +84,7 @@ struct wv_ctx {
         size_t traj_cap = 0;
         hipEvent_t copy_ev = nullptr;                // the copy of the planes to h_traj has finished
         hipEvent_t ev1 = nullptr;                    // after the last device work of the call
+        bool capture_all = false;                    // capture_frames == 2
         std::vector<hipEvent_t> kev;                 // kev[0] / kev[1] bracket the integrator launch(es); more when profiling
         bool pending = false;
         int nsteps = 0, planes = 0, impl = 0;
@@ -269,7 +275,7 @@ int wv_destroy(wv_ctx *c)
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     float *bufs[] = {c->d_x, c->d_y, c->d_sx, c->d_sy, c->d_frames, c->d_scratch[0], c->d_scratch[1], c->d_yA, c->d_yB,
-                     c->d_acc, c->d_G, c->d_plane[0], c->d_plane[1], c->d_traj, c->d_small, c->d_obs};
+                     c->d_acc, c->d_G, c->d_plane[0], c->d_plane[1], c->d_traj, c->d_small, c->d_obs, c->d_seq_frames};
     for (float *b : bufs)
         if (b) (void)hipFree(b);
     if (c->d_cyl) (void)hipFree(c->d_cyl);
@@ -548,6 +554,44 @@ int wv_observation(wv_ctx *c, int rx, int ry, float *out)
     return WV_OK;
 }
 
+// the three frames of action `action` of the last call that kept every action's frames (the last action's are env.wave)
+static const float *action_frames(wv_ctx *c, int action)
+{
+    if (action < 0 || action >= c->seq_frames_actions) return nullptr;
+    return action == c->seq_frames_actions - 1 ? c->d_frames : c->d_seq_frames + (size_t)action * 3 * c->N;
+}
+
+int wv_observation_action(wv_ctx *c, int action, int rx, int ry, float *out)
+{
+    CHECK_CTX(c);
+    if (!out) return fail(c, WV_ERR_INVALID, "wv_observation_action: NULL");
+    if (rx < 1 || ry < 1 || rx > c->nx || ry > c->ny)
+        return fail(c, WV_ERR_INVALID, "wv_observation_action: resolution must be within 1 .. grid size (src/env.jl:52)");
+    if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_observation_action: an integrate is pending");
+    const float *f = action_frames(c, action);
+    if (!f) return fail(c, WV_ERR_INVALID, "wv_observation_action: no such action in the last sequence call with capture_frames == 2");
+    const size_t n = (size_t)rx * ry * 4;
+    int rc = ensure(c, &c->d_obs, &c->obs_cap, n);
+    if (rc) return rc;
+    launch_observation(c->grid, f, f + c->N, f + 2 * c->N, c->has_source ? c->d_G : nullptr, rx, ry, c->d_obs, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->d_obs, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WV_OK;
+}
+
+int wv_get_frames_action(wv_ctx *c, int action, float *wave)
+{
+    CHECK_CTX(c);
+    if (!wave) return fail(c, WV_ERR_INVALID, "wv_get_frames_action: NULL");
+    if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_get_frames_action: an integrate is pending");
+    const float *f = action_frames(c, action);
+    if (!f) return fail(c, WV_ERR_INVALID, "wv_get_frames_action: no such action in the last sequence call with capture_frames == 2");
+    HIPCHK(c, hipMemcpyAsync(wave, f, 3 * c->N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WV_OK;
+}
+
 int wv_set_design(wv_ctx *c, int M, const float *pos_i, const float *r_i, const float *c_i, const float *pos_f,
                   const float *r_f, const float *c_f, float ti, float tf)
 {
@@ -720,6 +764,13 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     if (seq_n > 0 && (long long)seq_n * sps != nsteps)
         return fail(c, WV_ERR_INVALID, "wv_integrate: nsteps must be n_actions * steps_per_action of wv_set_design_sequence");
     if (seq_n > 0 && want_fields) return fail(c, WV_ERR_INVALID, "wv_integrate: a design sequence returns no trajectories");
+    const bool capture_all = capture == 2;  // the frames of EVERY action of a sequence
+    if (capture_all && (seq_n < 1 || sps <= 2 * WV_FRAMESKIP))
+        return fail(c, WV_ERR_INVALID, "wv_integrate: capture_frames == 2 needs a design sequence with more than 20 steps per action");
+    if (capture_all && c->n_pending)
+        return fail(c, WV_ERR_STATE, "wv_integrate_begin: a call that keeps every action's frames is not overlapped with another");
+    if (c->n_pending == 1 && c->slot[(c->next_slot + 1) % 2].capture_all)
+        return fail(c, WV_ERR_STATE, "wv_integrate_begin: the pending call keeps every action's frames: end it first");
     if (capture && nsteps < 2 * WV_FRAMESKIP)
         return fail(c, WV_ERR_INVALID,
                     "wv_integrate: capture_frames needs nsteps >= 20 (sol[:, :, :, end-20:10:end], src/env.jl:116)");
@@ -848,6 +899,22 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
             row0 = q.d_epart;
         }
     }
+    if (capture_all) {
+        const size_t need = (size_t)(seq_n - 1) * 3 * c->N;
+        const size_t had = c->seq_frames_cap;
+        if (need > 0) {
+            rc = ensure(c, &c->d_seq_frames, &c->seq_frames_cap, need);
+            if (rc) return rc;
+        }
+        if (c->seq_frames_cap != had) c->seq_frames_clean = false;
+        const bool reduced = impl == WV_IMPL_FUSED && fused_reduced(c->fused);
+        if (need > 0 && reduced && !c->seq_frames_clean) {  // (tiles with reduced field sets write 6 or 8 of the 12 planes)
+            HIPCHK(c, hipMemsetAsync(c->d_seq_frames, 0, c->seq_frames_cap * sizeof(float), st));
+            c->seq_frames_clean = true;
+        }
+        if (!reduced && impl == WV_IMPL_FUSED) c->seq_frames_clean = false;
+    }
+    c->seq_frames_actions = 0;  // (set when the call has been enqueued)
     if (want_fields) launch_copy_planes(cur, c->P, tt, ti_, st);
     if (capture && nsteps == 2 * WV_FRAMESKIP)
         HIPCHK(c, hipMemcpyAsync(frame(c, 0), cur, c->N * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -858,7 +925,14 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     c->fsteps.clear();
     for (int s = 1; s <= nsteps; ++s) {
         float *out;
-        if (capture && s == nsteps - 2 * WV_FRAMESKIP) out = frame(c, 0);
+        // (capture_all: action a = (s - 1) / sps ends at step (a + 1) * sps; its frames go to their own buffers)
+        const int act_s = capture_all ? (s - 1) / sps : 0;
+        const int rel = capture_all ? s - act_s * sps : 0;
+        float *const fa = (capture_all && act_s < seq_n - 1) ? c->d_seq_frames + (size_t)act_s * 3 * c->N : nullptr;
+        if (fa && rel == sps - 2 * WV_FRAMESKIP) out = fa;
+        else if (fa && rel == sps - WV_FRAMESKIP) out = fa + c->N;
+        else if (fa && rel == sps) out = fa + 2 * c->N;
+        else if (capture && s == nsteps - 2 * WV_FRAMESKIP) out = frame(c, 0);
         else if (capture && s == nsteps - WV_FRAMESKIP) out = frame(c, 1);
         else if (s == nsteps) out = frame(c, 2);
         else out = (cur == c->d_scratch[0]) ? c->d_scratch[1] : c->d_scratch[0];
@@ -965,6 +1039,8 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     HIPCHK(c, hipGetLastError());
 
     q.pending = true;
+    q.capture_all = capture_all;
+    if (capture_all) c->seq_frames_actions = seq_n;
     q.nsteps = nsteps;
     q.want_signal = want_signal != 0;
     q.want_fields = want_fields != 0;

@@ -36,6 +36,9 @@ void fused_state_zeroed(FusedPlan *p);
 // the 6-field fast path applies).  fused_generation changes whenever the decomposition does.
 int fused_energy_blocks(FusedPlan *p);
 int fused_generation(const FusedPlan *p);
+// after fused_prepare: the tiles use reduced field sets, i.e. every buffer a step writes to must hold zeros in the planes a
+// tile does not write
+bool fused_reduced(const FusedPlan *p);
 void fused_dump_stamps(FusedPlan *p, hipStream_t s);  // diagnostic, no-op unless WAVES_AMD_STAMPS is set
 // Called once per wv_integrate before the first step: d_table = device cylinder table (rows x M), h_table its host copy.
 // frames = env.wave (3 states, the last one is the initial condition), scratch0/1 the two ping-pong states.

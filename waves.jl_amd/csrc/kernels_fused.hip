@@ -1028,6 +1028,7 @@ static int fused_run_steps(FusedPlan *pl, int slot, const FusedCall &call, const
 }
 
 int fused_generation(const FusedPlan *p) { return p->generation; }
+bool fused_reduced(const FusedPlan *p) { return p->tiles_aux_zero; }
 void fused_allow_resident(FusedPlan *p, bool allow) { p->allow_resident = allow; }
 bool fused_last_resident(const FusedPlan *p) { return p->last_resident; }
 

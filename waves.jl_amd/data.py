@@ -127,15 +127,39 @@ def prepare_data(ep, horizon: int):
 
 
 def generate_episode(policy, env, *, reset: bool = True, with_states: bool = False, verbose: bool = False,
-                     in_flight: int = 2) -> Episode:
+                     in_flight: int = 2, per_launch: int | None = None) -> Episode:
     """generate_episode!(policy, env)  src/data.jl:12-33.  `with_states=True` records `state(env)` before every action
     like the reference does (the observation is resized on the device: 256 KB per action); the default skips it, which is
     all the energy-trace benchmarks need.  Without states nothing in the loop reads the wave, so two actions are kept in
     flight (`in_flight=2`: the host prepares action k+1 while action k runs; valid for policies that do not look at the
-    wave state, like the reference's RandomDesignPolicy); `in_flight=1` is the plain sequential loop."""
+    wave state, like the reference's RandomDesignPolicy); `in_flight=1` is the plain sequential loop.
+    `per_launch=n` hands n actions at a time to ONE device call (WaveEnv.steps_begin, wv_set_design_sequence; again for
+    policies that do not read the wave state): the launch start-up and the gap between launches are paid once per n
+    actions, and with `with_states=True` the frames of every action are kept on the device, so that the episode holds
+    the very states the plain loop records (state(env) in front of every action)."""
     s, a, t, y = [], [], [], []
     if reset:
         env.reset()
+    if per_launch:
+        keep = env.return_fields
+        env.return_fields = False
+        try:
+            while not env.is_terminated():
+                left = env.actions - env.time_step // env.integration_steps
+                m = max(1, min(int(per_launch), left))
+                if with_states:
+                    s.append(env.state())
+                acts = [policy(env) for _ in range(m)]
+                a += acts
+                t += env.steps_begin(acts, keep_frames=with_states)
+                y += [np.array(v) for v in env.steps_end()]
+                if with_states:
+                    s += [env.state_after(k) for k in range(m - 1)]
+                if verbose:
+                    print(env.time_step)
+        finally:
+            env.return_fields = keep
+        return Episode(s, a, t, y)
     keep = env.return_fields
     env.return_fields = False  # the rollout discards the returned fields (src/data.jl:27)
     depth = 1 if with_states else max(1, min(2, int(in_flight)))

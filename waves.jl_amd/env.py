@@ -106,11 +106,13 @@ class WaveEnv:
         self.design = next_design
         self.time_step += self.integration_steps
 
-    def steps_begin(self, actions):
+    def steps_begin(self, actions, keep_frames=False):
         """`for a in actions; env(a); end` (src/data.jl:22-27) enqueued as ONE device call: valid when the actions do not
         depend on the wave state in between (RandomDesignPolicy, src/env.jl:151-157).  The launch start-up and the gap
         between two launches are paid once for all of them (wv_set_design_sequence).  env.design / env.time_step advance
-        here as in step_begin; steps_end returns every action's signal; env.wave holds the frames of the LAST action."""
+        here as in step_begin; steps_end returns every action's signal; env.wave holds the frames of the LAST action.
+        keep_frames=True keeps the frames of every action on the device (state_after(k): what state(env) returned after
+        action k in the plain loop); such a call is not overlapped with another one."""
         if self.return_fields:
             raise ValueError("steps_begin: trajectories are per action -- use step_begin / step_end")
         if self.integration_steps < 2 * FRAMESKIP:
@@ -129,10 +131,22 @@ class WaveEnv:
         if stk[0] is None:
             raise ValueError("steps_begin: NoDesign has nothing to move -- use step_begin")
         self.ctx.set_design_sequence([(c.pos, c.r, c.c) for c in stk], [(i.ti, i.tf) for i in interps], self.integration_steps)
-        self.ctx.integrate_sequence_begin(np.stack(tspans), capture_frames=True, want_signal=True)
+        self.ctx.integrate_sequence_begin(np.stack(tspans), capture_frames="all" if keep_frames else True, want_signal=True)
         if not hasattr(self, "_pending") or self._pending is None:
             self._pending = []
         self._pending.append((tspans, interps))
+        self._seq_designs = designs[1:] if keep_frames else None   # env.design after every action
+        return tspans
+
+    def state_after(self, k):
+        """state(env) (src/env.jl:132-137) as the plain loop would have returned it after action k of the last
+        steps_begin(..., keep_frames=True): the frames of that action, resized on the device, and the design then in force."""
+        if not getattr(self, "_seq_designs", None):
+            raise RuntimeError("state_after: the last steps_begin did not keep every action's frames")
+        x = self.ctx.observation_action(k, *self.resolution)
+        n = self.integration_steps
+        t0 = f32(f32(self.time_step - (len(self._seq_designs) - 1 - k) * n) * self.dt)
+        return WaveEnvState(self.dim, build_tspan(t0, self.dt, n), x, self._seq_designs[k])
 
     def steps_end(self):
         """Second half of steps_begin: the list of every action's env.signal (src/env.jl:114); env.signal is the last."""
