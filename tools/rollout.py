@@ -16,6 +16,8 @@ def main():
     ap.add_argument("--actions", type=int, default=20)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--grid", type=int, default=700)
+    ap.add_argument("--per-launch", type=int, default=0,
+                    help="actions per device call (wv_set_design_sequence; 0 = one call per action, two in flight)")
     args = ap.parse_args()
     import torch
     import waves_jl_amd as w
@@ -35,7 +37,7 @@ def main():
         env.rng = np.random.default_rng(e)               # episode e is the same whichever rank runs it
         src.rng = np.random.default_rng(10_000 + e)
         pol = w.RandomDesignPolicy(env.action_space(), np.random.default_rng(20_000 + e))
-        ep = w.generate_episode(pol, env)
+        ep = w.generate_episode(pol, env, per_launch=args.per_launch or None)
         y = np.stack(ep.y)                               # (actions, steps+1, 3)
         rows.append([e, float(y.sum()), float(y[-1, -1, 0]), float(y[-1, -1, 2])])
     torch.cuda.synchronize()
@@ -48,7 +50,7 @@ def main():
         allrows = allrows[~np.isnan(allrows[:, 0])]
         cu = args.episodes * args.actions * args.steps * args.grid * args.grid
         print(json.dumps({"episodes": args.episodes, "actions": args.actions, "steps_per_action": args.steps,
-                          "grid": args.grid, "n_gpus": world, "seconds": round(dt, 3),
+                          "grid": args.grid, "n_gpus": world, "actions_per_launch": args.per_launch or 1, "seconds": round(dt, 3),
                           "Mcell_updates_per_s": round(cu / dt / 1e6, 1),
                           "episodes_table[id,reward,tot_energy_end,sc_energy_end]": allrows.round(4).tolist()}))
     wd.finalize()
