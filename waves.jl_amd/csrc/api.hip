@@ -825,7 +825,10 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
         c->elast_valid = false;
     }
     if (impl == WV_IMPL_FUSED) {
-        fused_allow_resident(c->fused, g_live_ctx[c->cfg.device & 63] <= 1);
+        // (WAVES_AMD_FORCE_RESIDENT=1: experiments with several co-resident resident kernels -- the caller answers for
+        // the sum of their tiles fitting the device's block slots)
+        static const bool force_res = getenv("WAVES_AMD_FORCE_RESIDENT") && atoi(getenv("WAVES_AMD_FORCE_RESIDENT")) != 0;
+        fused_allow_resident(c->fused, force_res || g_live_ctx[c->cfg.device & 63] <= 1);
         rc = fused_prepare(c->fused, si, c->d_frames, c->d_scratch[0], c->d_scratch[1], capture != 0,
                            c->has_source ? c->d_G : nullptr, q.d_cyl, M > 0 ? q.h_cyl : nullptr, M, 3 * nsteps, st, up, row_lo,
                            row_hi);
