@@ -28,6 +28,9 @@ def init(backend: str | None = None):
         return rank, local_rank, world
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # a rehearsal with several ranks on ONE GPU (WAVES_AMD_ALLOW_SHARED_GPU=1): RCCL refuses two ranks on a device
+        if backend == "nccl" and os.environ.get("WAVES_AMD_ALLOW_SHARED_GPU") and torch.cuda.device_count() < world:
+            backend = "gloo"
     if backend == "nccl":
         n = torch.cuda.device_count()
         if n == 0:
