@@ -1007,6 +1007,11 @@ WV_HD void fused_store(const FusedParams &p, const StepIO &io, const TileDesc &t
     constexpr int NS = aux_ns(AUX);
     const int lane = tid & 63, w = wv_wave_of(tid);
     e[0] = e[1] = e[2] = 0.0f;
+    // The step's output pointers ONCE, in front of the rows: read through `io` inside the row loop they were fetched again
+    // for every row (the output stores in between might alias the table, as far as the compiler knows) -- three dependent
+    // scalar-memory round trips per row and wave, ~0.5 us per step of pure waiting.
+    float *const io_out = io.out, *const io_tt = io.traj_tot, *const io_ti = io.traj_inc;
+    const unsigned nx_ = (unsigned)p.nx;
     if (lane < FT_H || lane >= FT_H + t.ox) return;
     const int gx = t.x0 - FT_H + lane;
 #pragma unroll
@@ -1014,13 +1019,13 @@ WV_HD void fused_store(const FusedParams &p, const StepIO &io, const TileDesc &t
         const int ly = w + NW * rr;
         if (ly < FT_H || ly >= FT_H + t.oy) continue;
         const int gy = t.y0 - FT_H + ly;
-        const unsigned id = (unsigned)gy * (unsigned)p.nx + (unsigned)gx;
-        if (io.out) {  // block-uniform: a resident tile only writes the states somebody reads (frames, the last step)
+        const unsigned id = (unsigned)gy * nx_ + (unsigned)gx;
+        if (io_out) {  // block-uniform: a resident tile only writes the states somebody reads (frames, the last step)
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int j = 0; j < NS; ++j) {
-                    float *plane = io.out + (size_t)(6 * s + aux_plane(AUX, j)) * p.P;
+                    float *plane = io_out + (size_t)(6 * s + aux_plane(AUX, j)) * p.P;
                     store_out(plane + id, r.y[rr][s][j]);
                 }
         }
@@ -1030,8 +1035,8 @@ WV_HD void fused_store(const FusedParams &p, const StepIO &io, const TileDesc &t
         e[0] = __builtin_fmaf(ut, ut, e[0]);
         e[1] = __builtin_fmaf(ui, ui, e[1]);
         e[2] = __builtin_fmaf(us, us, e[2]);
-        if (io.traj_tot) io.traj_tot[id] = ut;
-        if (io.traj_inc) io.traj_inc[id] = ui;
+        if (io_tt) io_tt[id] = ut;
+        if (io_ti) io_ti[id] = ui;
     }
 }
 
