@@ -134,23 +134,50 @@ def free_port() -> int:
         return so.getsockname()[1]
 
 
-def spawn_ranks(n: int) -> int:
+def spawn_ranks(n: int, argv=None, poll_s: float = 0.05) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (this parent never touches a
-    GPU, so nothing that initialised HIP is ever replaced), relay rank 0's JSON line, exit with the worst return code."""
+    GPU, so nothing that initialised HIP is ever replaced), relay rank 0's JSON line, exit with the worst return code.
+    ALL children are watched: when one exits non-zero the others -- which would sit in a collective until somebody's time
+    limit -- are terminated (then killed) within seconds and the parent returns non-zero."""
     import subprocess
+    import tempfile
     port = os.environ.get("MASTER_PORT") or str(free_port())
+    argv = [os.path.abspath(__file__)] + sys.argv[1:] if argv is None else list(argv)
     procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")  # (a file, not a pipe: nobody has to drain it while we poll)
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for pr in procs[1:]:
-        rc = max(rc, abs(pr.wait()))
-    if out0:
-        sys.stdout.write(out0)
+        procs.append(subprocess.Popen([sys.executable] + argv, env=env, stdout=out0 if r == 0 else subprocess.DEVNULL, text=True))
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0:
+                rc = max(rc, abs(code))
+                print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                for o in sorted(live):
+                    procs[o].terminate()           # exactly the PIDs started above
+                t_end = time.monotonic() + 5.0
+                for o in sorted(live):
+                    try:
+                        procs[o].wait(timeout=max(0.1, t_end - time.monotonic()))
+                    except subprocess.TimeoutExpired:
+                        procs[o].kill()
+                        procs[o].wait()
+                live.clear()
+                break
+        if live:
+            time.sleep(poll_s)
+    out0.seek(0)
+    text = out0.read()
+    out0.close()
+    if text:
+        sys.stdout.write(text)
         sys.stdout.flush()
     return rc
 
@@ -215,6 +242,9 @@ class StubCtx:
                 "resident": True}
 
     def set_profiling(self, on):
+        pass
+
+    def synchronize(self):
         pass
 
     def close(self):
@@ -395,6 +425,8 @@ def main():
                 kern_ms += t_["step_kernel_ms"]
                 kern_launches += t_["step_kernel_launches"]
     all_sig = wd.gather_signals(np.stack(sigs))
+    for en in envs:          # (the library's own sync point: a resident launch that is waiting for further actions leaves now,
+        en.ctx.synchronize()  # instead of being waited out by the device-wide synchronisation below)
     sync_device()
     wd.barrier()
     assert len(all_sig) == world

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WV_ABI_VERSION 2
+#define WV_ABI_VERSION 3
 #define WV_NFIELDS 12 /* src/dynamics.jl:185-187 */
 #define WV_NFRAMES 3  /* src/env.jl:54,116 */
 #define WV_FRAMESKIP 10 /* src/env.jl:90 */
@@ -79,7 +79,15 @@ typedef struct wv_timing {
     int step_kernel_launches;
     int steps;
     int impl;               /* implementation that ran */
-    int resident;           /* 1: all steps ran in ONE launch of the resident kernel (step_kernel_launches == 1) */
+    int resident;           /* 1: all steps ran as ONE job of the resident kernel (step_kernel_launches == 1); total_ms and
+                             * step_kernel_ms are then the kernel's own clock stamps around the job (100 MHz device clock: job
+                             * seen by the launch -> state, frames and trace complete), because a resident launch may serve
+                             * many calls and HIP events only see the launch */
+    int gave_up;            /* 1: the resident kernel abandoned the call (a tile waited in vain for a neighbour: the device is
+                             * shared with somebody else's kernels); the call was then run again, transparently, by the
+                             * single-step kernels from its untouched initial condition, and the context stays on them */
+    double launch_ms;       /* the resident LAUNCH that ended last on this ctx: its duration by HIP events ... */
+    int launch_jobs;        /* ... and the number of wv_integrate calls it served (0: none has ended yet) */
 } wv_timing;
 
 int wv_abi_version(void);
@@ -190,6 +198,10 @@ int wv_set_trajectory_stride(wv_ctx *ctx, int stride);
 int wv_integrate_begin(wv_ctx *ctx, const float *tspan, int nsteps, int capture_frames, int want_signal,
                        int want_fields);
 int wv_integrate_end(wv_ctx *ctx, float *signal, float *u_tot, float *u_inc);
+/* Calls begun and not yet ended (0, 1 or 2).  An _end that fails with an argument / sequence error leaves its call pending;
+ * one that fails after the device work was waited for has ended it: a binding that mirrors the queue (the Python one does)
+ * asks here instead of guessing.  No reference counterpart (the reference's step is synchronous, src/env.jl:91-121). */
+int wv_pending(wv_ctx *ctx, int *count);
 /* Trajectory streaming (render! / build_interpolator, src/plot.jl:24-45, need u_tot / u_inc of src/env.jl:120 on the
  * host): with want_fields == 2 in _begin the planes of a call are copied to pinned host memory on a copy stream as soon
  * as its kernels have finished -- i.e. while the NEXT call (begun before this one is ended) computes -- instead of being

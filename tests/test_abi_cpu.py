@@ -25,7 +25,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert len(syms) >= 30
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/waves_amd.h but not exported"
-    assert _ffi.lib().wv_abi_version() == 2
+    assert _ffi.lib().wv_abi_version() == 3
 
 
 def test_ffi_binds_every_declared_symbol():
@@ -37,7 +37,7 @@ def test_ffi_binds_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_ffi.wv_config) == 32
-    assert ctypes.sizeof(_ffi.wv_timing) == 32
+    assert ctypes.sizeof(_ffi.wv_timing) == 56   # ABI 3: + gave_up, launch_ms, launch_jobs
 
 
 def test_no_cpu_fallback(gpu_available):

@@ -111,3 +111,58 @@ def test_bench_without_gpu_fails_only_at_context_creation():
                        env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
     assert r.returncode != 0
     assert "status 3" in r.stderr and "no CPU fallback" in r.stderr
+
+
+def test_ranks_that_share_a_gpu_are_kept_off_the_resident_kernel(monkeypatch):
+    """ADVICE r2 / VERDICT r2 item 3: whoever calls dist.init (bench.py, tools/rollout.py, a user script) with more ranks
+    than GPUs gets WAVES_AMD_FUSED_RESIDENT=0 BEFORE any Context exists -- two processes' resident grids on one device can
+    each end up partly resident.  The rule itself is a pure function; init applies it (no rendezvous needed to see that:
+    the variable is set before the backend is chosen, and init_process_group is stubbed out here)."""
+    import torch
+    import torch.distributed as tdist
+    assert wd.shares_device(2, 0, 1) and wd.shares_device(2, 1, 1) and wd.shares_device(8, 7, 4)
+    assert not wd.shares_device(2, 1, 2) and not wd.shares_device(1, 0, 1) and not wd.shares_device(8, 7, 8)
+    assert not wd.shares_device(2, 0, 0)          # a CPU-only run (gloo tests): nothing to share
+    for ndev, world, lrank, want in ((1, 2, 0, "0"), (1, 2, 1, "0"), (2, 2, 1, None), (8, 8, 3, None)):
+        monkeypatch.delenv("WAVES_AMD_FUSED_RESIDENT", raising=False)
+        monkeypatch.setenv("WORLD_SIZE", str(world))
+        monkeypatch.setenv("RANK", str(lrank))
+        monkeypatch.setenv("LOCAL_RANK", str(lrank))
+        monkeypatch.setenv("WAVES_AMD_ALLOW_SHARED_GPU", "1")
+        monkeypatch.setattr(torch.cuda, "device_count", lambda n=ndev: n)
+        monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+        monkeypatch.setattr(tdist, "is_initialized", lambda: True)   # (skip the rendezvous)
+        assert wd.init() == (lrank, lrank, world)
+        assert os.environ.get("WAVES_AMD_FUSED_RESIDENT") == want, (ndev, world, lrank)
+
+
+def test_spawn_ranks_returns_within_seconds_when_a_rank_dies():
+    """`bench.py --gpus N` self-spawned watches ALL its children.  Rank 1 exits with code 3 at once while
+    rank 0 would sit (here: sleeps) for a minute: the parent stops rank 0 and returns non-zero in well under 10 s."""
+    import importlib.util
+    import tempfile
+    import time
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write("import os, sys, time\n"
+                "if os.environ['RANK'] == '1':\n    sys.exit(3)\n"
+                "print('rank 0 waits in its collective', flush=True)\ntime.sleep(60)\n")
+        stub = f.name
+    try:
+        t0 = time.monotonic()
+        rc = bench.spawn_ranks(2, argv=[stub])
+        dt = time.monotonic() - t0
+    finally:
+        os.unlink(stub)
+    assert rc == 3
+    assert dt < 10.0, dt
+    # ... and a clean pair still returns 0 with rank 0's output relayed
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write("import os\nprint('hello from', os.environ['RANK'], flush=True)\n")
+        stub = f.name
+    try:
+        assert bench.spawn_ranks(2, argv=[stub]) == 0
+    finally:
+        os.unlink(stub)

@@ -21,8 +21,8 @@ def main():
     sel = [int(v) for v in sys.argv[2:]] or list(range(len(VARIANTS)))
     os.makedirs(OUT, exist_ok=True)
     src = open(os.path.join(CS, "kernels_fused.hip")).read()
-    k = src.index("void %s(FusedParams p_)" % kern)
-    a = src.index("    if (t.aux == AUX_NONE) {", k)
+    k = src.index("void %s(%s)" % (kern, "JobArgs a_" if kern == "k_steps_resident" else "FusedParams p_"))
+    a = src.index("if (t.aux == AUX_NONE) {", k)
     b = src.index("#undef RUN", a)
     procs = []
     for i in sel:
@@ -30,7 +30,7 @@ def main():
         path = os.path.join(OUT, "v%d.hip" % i)
         open(path, "w").write(src[:a] + "    RUN(%s, %s, %s); (void)fl; (void)fe; (void)cyl;\n" % (A, F, R) + src[b:])
         cmd = ("hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 -I%s -I%s/include "
-               "%s -c %s -o %s.o -Rpass-analysis=kernel-resource-usage 2> %s.txt" % (CS, ROOT, os.environ.get("WV_DEFS", ""), path, path, path))
+               "%s -c %s -o %s.o -save-temps=obj -Rpass-analysis=kernel-resource-usage 2> %s.txt" % (CS, ROOT, os.environ.get("WV_DEFS", ""), path, path, path))
         procs.append(subprocess.Popen(cmd, shell=True))
         if len(procs) >= 6:
             procs.pop(0).wait()

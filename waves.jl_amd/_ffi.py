@@ -40,7 +40,8 @@ class wv_latent_config(C.Structure):
 
 class wv_timing(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("step_kernel_ms", C.c_double), ("step_kernel_launches", C.c_int),
-                ("steps", C.c_int), ("impl", C.c_int), ("resident", C.c_int)]
+                ("steps", C.c_int), ("impl", C.c_int), ("resident", C.c_int), ("gave_up", C.c_int), ("launch_ms", C.c_double),
+                ("launch_jobs", C.c_int)]
 
 
 _fp = C.POINTER(C.c_float)
@@ -105,6 +106,7 @@ def lib():
     _sig(L, "wv_integrate", [ctx, _fp, C.c_int, C.c_int, _fp, _fp, _fp])
     _sig(L, "wv_integrate_begin", [ctx, _fp, C.c_int, C.c_int, C.c_int, C.c_int])
     _sig(L, "wv_integrate_end", [ctx, _fp, _fp, _fp])
+    _sig(L, "wv_pending", [ctx, C.POINTER(C.c_int)])
     _sig(L, "wv_integrate_end_view", [ctx, _fp, C.POINTER(_fp), C.POINTER(_fp), C.POINTER(C.c_int)])
     _sig(L, "wv_set_trajectory_stride", [ctx, C.c_int])
     _sig(L, "wv_set_profiling", [ctx, C.c_int])
@@ -345,6 +347,17 @@ class Context:
     def pending(self) -> int:
         return len(getattr(self, "_pend", ()))
 
+    def _end_ck(self, rc):
+        """Status check of an integrate_end: on failure the mirror of the library's queue of pending calls is brought
+        back in line with the library's own count (an _end that failed after the device work was waited for HAS ended
+        its call; an argument error has not) before the error is raised."""
+        if rc != WV_OK:
+            n = C.c_int(0)
+            if self._L.wv_pending(self._h, C.byref(n)) == WV_OK:
+                while len(self._pend) > n.value:
+                    self._pend.pop(0)
+        self._ck(rc)
+
     def integrate_end(self):
         if not getattr(self, "_pend", None):  # nothing pending: let the library say so (WV_ERR_STATE)
             self._ck(self._L.wv_integrate_end(self._h, None, None, None))
@@ -352,7 +365,7 @@ class Context:
         sig = np.empty((n + 1, 3), np.float32) if ws else None
         if wf == "stream":   # zero-copy views of the library's pinned planes (valid until the second integrate_begin from now)
             pt, pi, npl = _fp(), _fp(), C.c_int(0)
-            self._ck(self._L.wv_integrate_end_view(self._h, fptr(sig), C.byref(pt), C.byref(pi), C.byref(npl)))
+            self._end_ck(self._L.wv_integrate_end_view(self._h, fptr(sig), C.byref(pt), C.byref(pi), C.byref(npl)))
             self._pend.pop(0)
             shape = (npl.value, self.ny, self.nx)
             ut = np.ctypeslib.as_array(pt, shape).transpose(2, 1, 0)
@@ -361,7 +374,7 @@ class Context:
         planes = n // getattr(self, "_traj_stride", 1) + 1
         ut = np.empty((self.nx, self.ny, planes), np.float32, order="F") if wf else None
         ui = np.empty((self.nx, self.ny, planes), np.float32, order="F") if wf else None
-        self._ck(self._L.wv_integrate_end(self._h, fptr(sig), fptr(ut), fptr(ui)))
+        self._end_ck(self._L.wv_integrate_end(self._h, fptr(sig), fptr(ut), fptr(ui)))
         self._pend.pop(0)
         return sig, ut, ui
 
@@ -374,7 +387,8 @@ class Context:
         self._ck(self._L.wv_get_timing(self._h, C.byref(t)))
         return {"total_ms": t.total_ms, "step_kernel_ms": t.step_kernel_ms,
                 "step_kernel_launches": t.step_kernel_launches, "steps": t.steps,
-                "impl": {1: "staged", 2: "fused"}.get(t.impl, str(t.impl)), "resident": bool(t.resident)}
+                "impl": {1: "staged", 2: "fused"}.get(t.impl, str(t.impl)), "resident": bool(t.resident),
+                "gave_up": bool(t.gave_up), "launch_ms": t.launch_ms, "launch_jobs": t.launch_jobs}
 
     def set_stream(self, stream_handle):
         self._ck(self._L.wv_set_stream(self._h, _vp(stream_handle) if stream_handle else None))

@@ -9,6 +9,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -28,7 +29,10 @@ struct wv_ctx {
     Grid grid{};
 
     float *d_x = nullptr, *d_y = nullptr, *d_sx = nullptr, *d_sy = nullptr;
-    float *d_frames = nullptr;           // env.wave: 3 states
+    float *d_frames = nullptr;           // env.wave: 3 states ...
+    float *d_f2alt = nullptr;            // ... whose LAST one lives alternately there ("home") and here: a call reads its initial
+    int cur2 = 0;                        // condition from one and writes its final state to the other (0: home, 1: d_f2alt), so
+                                         // that a call the resident kernel gives up can simply be run again
     float *d_scratch[2] = {nullptr, nullptr};
     float *d_yA = nullptr, *d_yB = nullptr, *d_acc = nullptr;  // staged implementation only
     float *d_G = nullptr;                // source shape
@@ -86,9 +90,14 @@ struct wv_ctx {
         hipEvent_t ev1 = nullptr;                    // after the last device work of the call
         bool capture_all = false;                    // capture_frames == 2
         std::vector<hipEvent_t> kev;                 // kev[0] / kev[1] bracket the integrator launch(es); more when profiling
+        // what running the call once more needs (after the resident kernel gave it up)
+        std::vector<FusedStep> fsteps;
+        FusedCall fcall{};
+        const float *row0 = nullptr;
+        int nblocks = 0;
         bool pending = false;
         int nsteps = 0, planes = 0, impl = 0;
-        bool want_signal = false, want_fields = false, streamed = false, bracketed = false, resident = false;
+        bool want_signal = false, want_fields = false, streamed = false, bracketed = false, resident = false, gave_up = false;
         int prof_launches = 0, prof_events = 0;
     } slot[2];
     int next_slot = 0;   // slot of the next wv_integrate_begin
@@ -132,6 +141,13 @@ static int fail(wv_ctx *c, int code, const std::string &msg)
     do {                                               \
         if (!(c)) return fail(nullptr, WV_ERR_INVALID, "ctx is NULL"); \
         HIPCHK((c), hipSetDevice((c)->cfg.device));    \
+    } while (0)
+
+// Entry points that use the context's stream (or let the caller touch the device state) first make a resident launch that
+// is waiting for further wv_integrate calls leave: work enqueued behind it would wait out its idle limit.
+#define QUIET(c)                                                                                                  \
+    do {                                                                                                          \
+        if ((c)->fused && fused_retire((c)->fused) != 0) return fail((c), WV_ERR_HIP, "the resident launch did not leave"); \
     } while (0)
 
 // ---- host-side restatement of the closures' scalar work (fp32, reference order, no FMA) -----------------------
@@ -238,7 +254,24 @@ static int ensure_pinned(wv_ctx *c, T **d, T **h, size_t *cap, size_t need)
     return WV_OK;
 }
 
-static float *frame(wv_ctx *c, int k) { return c->d_frames + (size_t)k * c->N; }
+static float *frame(wv_ctx *c, int k) { return (k == 2 && c->cur2) ? c->d_f2alt : c->d_frames + (size_t)k * c->N; }
+static float *other2(wv_ctx *c) { return c->cur2 ? c->d_frames + 2 * c->N : c->d_f2alt; }  // where the next call's final state goes
+// env.wave as ONE array again (raw-pointer access, wv_set_frames): the last frame back to its home
+static int frames_home(wv_ctx *c)
+{
+    if (c->cur2) {
+        hipError_t e = hipMemcpyAsync(c->d_frames + 2 * c->N, c->d_f2alt, c->N * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            c->err = std::string("frames_home: ") + hipGetErrorString(e);
+            return WV_ERR_HIP;
+        }
+        c->cur2 = 0;
+        fused_state_changed(c->fused);  // (which buffer holds what has changed: look again)
+        c->elast_valid = false;
+    }
+    return WV_OK;
+}
 
 // ---- ABI -------------------------------------------------------------------------------------------------
 
@@ -273,8 +306,9 @@ int wv_destroy(wv_ctx *c)
     if (!c) return WV_OK;
     if (c->counted) g_live_ctx[c->cfg.device & 63]--;
     (void)hipSetDevice(c->cfg.device);
+    if (c->fused) (void)fused_retire(c->fused);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    float *bufs[] = {c->d_x, c->d_y, c->d_sx, c->d_sy, c->d_frames, c->d_scratch[0], c->d_scratch[1], c->d_yA, c->d_yB,
+    float *bufs[] = {c->d_x, c->d_y, c->d_sx, c->d_sy, c->d_frames, c->d_f2alt, c->d_scratch[0], c->d_scratch[1], c->d_yA, c->d_yB,
                      c->d_acc, c->d_G, c->d_plane[0], c->d_plane[1], c->d_traj, c->d_small, c->d_obs, c->d_seq_frames};
     for (float *b : bufs)
         if (b) (void)hipFree(b);
@@ -366,6 +400,7 @@ int wv_create(const wv_config *cfg, const float *x, const float *y, wv_ctx **out
     CK(hipMalloc((void **)&c->d_sx, c->nx * sizeof(float)));
     CK(hipMalloc((void **)&c->d_sy, c->ny * sizeof(float)));
     CK(hipMalloc((void **)&c->d_frames, 3 * c->N * sizeof(float)));
+    CK(hipMalloc((void **)&c->d_f2alt, c->N * sizeof(float)));
     CK(hipMalloc((void **)&c->d_scratch[0], c->N * sizeof(float)));
     CK(hipMalloc((void **)&c->d_scratch[1], c->N * sizeof(float)));
     CK(hipMalloc((void **)&c->d_yA, c->N * sizeof(float)));
@@ -379,6 +414,7 @@ int wv_create(const wv_config *cfg, const float *x, const float *y, wv_ctx **out
     CK(hipMemcpy(c->d_sx, c->sx.data(), c->nx * sizeof(float), hipMemcpyHostToDevice));
     CK(hipMemcpy(c->d_sy, c->sy.data(), c->ny * sizeof(float), hipMemcpyHostToDevice));
     CK(hipMemset(c->d_frames, 0, 3 * c->N * sizeof(float)));
+    CK(hipMemset(c->d_f2alt, 0, c->N * sizeof(float)));
     // the reduced field sets of the fused kernel rely on unwritten planes of every output buffer holding zeros
     CK(hipMemset(c->d_scratch[0], 0, c->N * sizeof(float)));
     CK(hipMemset(c->d_scratch[1], 0, c->N * sizeof(float)));
@@ -419,6 +455,7 @@ int wv_get_pml(wv_ctx *c, float *sigma_x, float *sigma_y)
 int wv_set_pml(wv_ctx *c, const float *sigma_x, const float *sigma_y)
 {
     CHECK_CTX(c);
+    QUIET(c);
     if (!sigma_x || !sigma_y) return fail(c, WV_ERR_INVALID, "wv_set_pml: NULL profile");
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_set_pml: an integrate is pending");
     c->sx.assign(sigma_x, sigma_x + c->nx);
@@ -440,8 +477,10 @@ int wv_get_cell_area(wv_ctx *c, float *dOmega)
 int wv_set_frames(wv_ctx *c, const float *wave)
 {
     CHECK_CTX(c);
+    QUIET(c);
     if (!wave) return fail(c, WV_ERR_INVALID, "wv_set_frames: NULL");
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_set_frames: an integrate is pending");
+    c->cur2 = 0;
     HIPCHK(c, hipMemcpyAsync(c->d_frames, wave, 3 * c->N * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     fused_state_changed(c->fused);
@@ -452,8 +491,10 @@ int wv_set_frames(wv_ctx *c, const float *wave)
 int wv_get_frames(wv_ctx *c, float *wave)
 {
     CHECK_CTX(c);
+    QUIET(c);
     if (!wave) return fail(c, WV_ERR_INVALID, "wv_get_frames: NULL");
-    HIPCHK(c, hipMemcpyAsync(wave, c->d_frames, 3 * c->N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(wave, c->d_frames, 2 * c->N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(wave + 2 * c->N, frame(c, 2), c->N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return WV_OK;
 }
@@ -461,6 +502,7 @@ int wv_get_frames(wv_ctx *c, float *wave)
 int wv_set_state(wv_ctx *c, const float *u)
 {
     CHECK_CTX(c);
+    QUIET(c);
     if (!u) return fail(c, WV_ERR_INVALID, "wv_set_state: NULL");
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_set_state: an integrate is pending");
     HIPCHK(c, hipMemcpyAsync(frame(c, 2), u, c->N * sizeof(float), hipMemcpyHostToDevice, c->stream));
@@ -473,6 +515,7 @@ int wv_set_state(wv_ctx *c, const float *u)
 int wv_get_state(wv_ctx *c, float *u)
 {
     CHECK_CTX(c);
+    QUIET(c);
     if (!u) return fail(c, WV_ERR_INVALID, "wv_get_state: NULL");
     HIPCHK(c, hipMemcpyAsync(u, frame(c, 2), c->N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -482,7 +525,9 @@ int wv_get_state(wv_ctx *c, float *u)
 int wv_reset(wv_ctx *c)
 {
     CHECK_CTX(c);
+    QUIET(c);
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_reset: an integrate is pending");
+    c->cur2 = 0;
     HIPCHK(c, hipMemsetAsync(c->d_frames, 0, 3 * c->N * sizeof(float), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     fused_state_zeroed(c->fused);
@@ -493,6 +538,7 @@ int wv_reset(wv_ctx *c)
 int wv_set_source_shape(wv_ctx *c, const float *shape, float freq)
 {
     CHECK_CTX(c);
+    QUIET(c);
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_set_source_shape: an integrate is pending");
     c->has_source = shape != nullptr;
     c->freq = freq;
@@ -509,6 +555,7 @@ int wv_set_source_shape(wv_ctx *c, const float *shape, float freq)
 int wv_set_gaussian_source(wv_ctx *c, int K, const float *mu, const float *sigma, const float *a, float freq)
 {
     CHECK_CTX(c);
+    QUIET(c);
     if (K < 1 || !mu || !sigma || !a) return fail(c, WV_ERR_INVALID, "wv_set_gaussian_source: bad arguments");
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_set_gaussian_source: an integrate is pending");
     int rc = ensure(c, &c->d_small, &c->small_cap, (size_t)4 * K);
@@ -530,6 +577,7 @@ int wv_set_gaussian_source(wv_ctx *c, int K, const float *mu, const float *sigma
 int wv_get_source_shape(wv_ctx *c, float *shape)
 {
     CHECK_CTX(c);
+    QUIET(c);
     if (!shape) return fail(c, WV_ERR_INVALID, "wv_get_source_shape: NULL");
     HIPCHK(c, hipMemcpyAsync(shape, c->d_G, c->P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -539,6 +587,7 @@ int wv_get_source_shape(wv_ctx *c, float *shape)
 int wv_observation(wv_ctx *c, int rx, int ry, float *out)
 {
     CHECK_CTX(c);
+    QUIET(c);
     if (!out) return fail(c, WV_ERR_INVALID, "wv_observation: NULL");
     if (rx < 1 || ry < 1 || rx > c->nx || ry > c->ny)
         return fail(c, WV_ERR_INVALID, "wv_observation: resolution must be within 1 .. grid size (src/env.jl:52)");
@@ -555,25 +604,31 @@ int wv_observation(wv_ctx *c, int rx, int ry, float *out)
 }
 
 // the three frames of action `action` of the last call that kept every action's frames (the last action's are env.wave)
-static const float *action_frames(wv_ctx *c, int action)
+static bool action_frames(wv_ctx *c, int action, const float *f[3])
 {
-    if (action < 0 || action >= c->seq_frames_actions) return nullptr;
-    return action == c->seq_frames_actions - 1 ? c->d_frames : c->d_seq_frames + (size_t)action * 3 * c->N;
+    if (action < 0 || action >= c->seq_frames_actions) return false;
+    if (action == c->seq_frames_actions - 1) {
+        for (int k = 0; k < 3; ++k) f[k] = frame(c, k);
+    } else {
+        for (int k = 0; k < 3; ++k) f[k] = c->d_seq_frames + ((size_t)action * 3 + k) * c->N;
+    }
+    return true;
 }
 
 int wv_observation_action(wv_ctx *c, int action, int rx, int ry, float *out)
 {
     CHECK_CTX(c);
+    QUIET(c);
     if (!out) return fail(c, WV_ERR_INVALID, "wv_observation_action: NULL");
     if (rx < 1 || ry < 1 || rx > c->nx || ry > c->ny)
         return fail(c, WV_ERR_INVALID, "wv_observation_action: resolution must be within 1 .. grid size (src/env.jl:52)");
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_observation_action: an integrate is pending");
-    const float *f = action_frames(c, action);
-    if (!f) return fail(c, WV_ERR_INVALID, "wv_observation_action: no such action in the last sequence call with capture_frames == 2");
+    const float *f[3];
+    if (!action_frames(c, action, f)) return fail(c, WV_ERR_INVALID, "wv_observation_action: no such action in the last sequence call with capture_frames == 2");
     const size_t n = (size_t)rx * ry * 4;
     int rc = ensure(c, &c->d_obs, &c->obs_cap, n);
     if (rc) return rc;
-    launch_observation(c->grid, f, f + c->N, f + 2 * c->N, c->has_source ? c->d_G : nullptr, rx, ry, c->d_obs, c->stream);
+    launch_observation(c->grid, f[0], f[1], f[2], c->has_source ? c->d_G : nullptr, rx, ry, c->d_obs, c->stream);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out, c->d_obs, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -583,11 +638,12 @@ int wv_observation_action(wv_ctx *c, int action, int rx, int ry, float *out)
 int wv_get_frames_action(wv_ctx *c, int action, float *wave)
 {
     CHECK_CTX(c);
+    QUIET(c);
     if (!wave) return fail(c, WV_ERR_INVALID, "wv_get_frames_action: NULL");
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_get_frames_action: an integrate is pending");
-    const float *f = action_frames(c, action);
-    if (!f) return fail(c, WV_ERR_INVALID, "wv_get_frames_action: no such action in the last sequence call with capture_frames == 2");
-    HIPCHK(c, hipMemcpyAsync(wave, f, 3 * c->N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    const float *f[3];
+    if (!action_frames(c, action, f)) return fail(c, WV_ERR_INVALID, "wv_get_frames_action: no such action in the last sequence call with capture_frames == 2");
+    for (int k = 0; k < 3; ++k) HIPCHK(c, hipMemcpyAsync(wave + (size_t)k * c->N, f[k], c->N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return WV_OK;
 }
@@ -640,6 +696,7 @@ int wv_set_design_sequence(wv_ctx *c, int n_actions, int steps_per_action, int M
 int wv_speed_field(wv_ctx *c, float t, float *out)
 {
     CHECK_CTX(c);
+    QUIET(c);
     if (!out) return fail(c, WV_ERR_INVALID, "wv_speed_field: NULL");
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_speed_field: an integrate is pending");
     int rc = ensure(c, &c->d_cyl, &c->cyl_cap, (size_t)(c->M > 0 ? c->M : 1));
@@ -657,6 +714,7 @@ int wv_speed_field(wv_ctx *c, float t, float *out)
 int wv_source_field(wv_ctx *c, float t, float *out)
 {
     CHECK_CTX(c);
+    QUIET(c);
     if (!out) return fail(c, WV_ERR_INVALID, "wv_source_field: NULL");
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_source_field: an integrate is pending");
     if (!c->has_source) {  // NoSource returns the scalar 0f0 (src/sources.jl:8)
@@ -673,6 +731,7 @@ int wv_source_field(wv_ctx *c, float t, float *out)
 int wv_gradient(wv_ctx *c, int axis, const float *u, float *out)
 {
     CHECK_CTX(c);
+    QUIET(c);
     if (!u || !out || (axis != 0 && axis != 1)) return fail(c, WV_ERR_INVALID, "wv_gradient: bad arguments");
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_gradient: an integrate is pending");
     HIPCHK(c, hipMemcpyAsync(c->d_plane[0], u, c->P * sizeof(float), hipMemcpyHostToDevice, c->stream));
@@ -686,6 +745,7 @@ int wv_gradient(wv_ctx *c, int axis, const float *u, float *out)
 int wv_rhs(wv_ctx *c, const float *x, float t, float *k)
 {
     CHECK_CTX(c);
+    QUIET(c);
     if (!x || !k) return fail(c, WV_ERR_INVALID, "wv_rhs: NULL");
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_rhs: an integrate is pending");
     int rc = ensure(c, &c->d_cyl, &c->cyl_cap, (size_t)(c->M > 0 ? c->M : 1));
@@ -715,20 +775,39 @@ int wv_rhs(wv_ctx *c, const float *x, float t, float *k)
 
 // diagnostic (WAVES_AMD_HOSTPROF=1): where the host time of wv_integrate_begin goes, printed at exit
 namespace {
+// (contexts may be driven from different threads: with the diagnostic off -- every normal run -- nothing here is written;
+// with it on, the accumulators are shared under a mutex and the lap clock is the calling thread's own)
 struct HostProf {
-    bool on = getenv("WAVES_AMD_HOSTPROF") != nullptr;
+    const bool on = getenv("WAVES_AMD_HOSTPROF") != nullptr;
+    std::mutex mu;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long calls = 0;
-    std::chrono::steady_clock::time_point t;
-    void start() { if (on) t = std::chrono::steady_clock::now(); }
+    static std::chrono::steady_clock::time_point &clock()
+    {
+        static thread_local std::chrono::steady_clock::time_point t;
+        return t;
+    }
+    void start()
+    {
+        if (!on) return;
+        std::lock_guard<std::mutex> g(mu);
+        if (++calls == 6) {  // the first calls allocate / load code: not representative
+            for (double &a : acc) a = 0.0;
+            calls = 1;
+        }
+        clock() = std::chrono::steady_clock::now();
+    }
     void lap(int k)
     {
         if (!on) return;
         const auto n = std::chrono::steady_clock::now();
-        const double us = std::chrono::duration<double, std::micro>(n - t).count();
-        acc[k] += us;
+        const double us = std::chrono::duration<double, std::micro>(n - clock()).count();
+        {
+            std::lock_guard<std::mutex> g(mu);
+            acc[k] += us;
+        }
         if (us > 3000.0) fprintf(stderr, "[waves_amd hostprof] section %d of wv_integrate_begin took %.1f ms\n", k, us / 1000.0);
-        t = n;
+        clock() = n;
     }
     ~HostProf()
     {
@@ -745,10 +824,6 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
 {
     CHECK_CTX(c);
     g_hostprof.start();
-    if (++g_hostprof.calls == 6) {  // the first calls allocate / load code: not representative
-        for (double &a : g_hostprof.acc) a = 0.0;
-        g_hostprof.calls = 1;
-    }
     // Two calls may be in flight: the second one is prepared (tables, culling, uploads on the copy stream) and enqueued
     // while the first one runs; only the device state is sequentially dependent, and the stream orders that.
     if (c->n_pending >= 2) return fail(c, WV_ERR_STATE, "wv_integrate_begin: two integrates are already pending");
@@ -817,21 +892,36 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     if (!t_ok) row_lo = row_hi = -1;  // (a NaN time: let the culling look at every row)
     if (seq_n > 0) row_lo = row_hi = -1;  // (a sequence is not ONE monotone interpolation: every row)
     g_hostprof.lap(0);
-    if (M > 0) HIPCHK(c, hipMemcpyAsync(q.d_cyl, q.h_cyl, ncyl * sizeof(Cyl), hipMemcpyHostToDevice, up));
-    HIPCHK(c, hipMemcpyAsync(q.d_sfac, q.h_sfac, nsf * sizeof(float), hipMemcpyHostToDevice, up));
-    g_hostprof.lap(1);
     if (c->frames_exposed) {  // somebody holds the raw pointer of env.wave: assume it was written
         fused_state_changed(c->fused);
         c->elast_valid = false;
     }
+    // A resident launch that is still on the device (waiting for this very call, ideally) owns the stream: the call may be
+    // handed to it only if nothing has to run on the stream first.  Otherwise the launch is told to leave, and the call
+    // starts a new one behind its prerequisites.
+    static const bool force_res = getenv("WAVES_AMD_FORCE_RESIDENT") && atoi(getenv("WAVES_AMD_FORCE_RESIDENT")) != 0;
+    const bool may_stay = impl == WV_IMPL_FUSED && !c->profiling && !shared && c->stream == c->own_stream && want_fields == 0 &&
+                          !capture_all && !c->frames_exposed;
+    bool launch_there = impl == WV_IMPL_FUSED && fused_persist_alive(c->fused);
+    if (c->fused) {
+        const bool needs = !may_stay || (want_signal && !c->elast_valid) || (capture && nsteps == 2 * WV_FRAMESKIP) ||
+                           fused_needs_stream(c->fused, capture != 0, c->has_source ? c->d_G : nullptr, c->cur2 ^ 1);
+        if (needs || impl != WV_IMPL_FUSED) {
+            if (fused_retire(c->fused) != 0) return fail(c, WV_ERR_HIP, "wv_integrate_begin: the resident launch did not leave");
+            launch_there = false;
+        }
+    }
+    if (M > 0) HIPCHK(c, hipMemcpyAsync(q.d_cyl, q.h_cyl, ncyl * sizeof(Cyl), hipMemcpyHostToDevice, up));
+    HIPCHK(c, hipMemcpyAsync(q.d_sfac, q.h_sfac, nsf * sizeof(float), hipMemcpyHostToDevice, up));
+    g_hostprof.lap(1);
     if (impl == WV_IMPL_FUSED) {
         // (WAVES_AMD_FORCE_RESIDENT=1: experiments with several co-resident resident kernels -- the caller answers for
         // the sum of their tiles fitting the device's block slots)
-        static const bool force_res = getenv("WAVES_AMD_FORCE_RESIDENT") && atoi(getenv("WAVES_AMD_FORCE_RESIDENT")) != 0;
         fused_allow_resident(c->fused, force_res || g_live_ctx[c->cfg.device & 63] <= 1);
-        rc = fused_prepare(c->fused, si, c->d_frames, c->d_scratch[0], c->d_scratch[1], capture != 0,
+        fused_allow_persist(c->fused, may_stay);
+        rc = fused_prepare(c->fused, si, c->d_frames, frame(c, 2), other2(c), c->cur2 ^ 1, c->d_scratch[0], c->d_scratch[1], capture != 0,
                            c->has_source ? c->d_G : nullptr, q.d_cyl, M > 0 ? q.h_cyl : nullptr, M, 3 * nsteps, st, up, row_lo,
-                           row_hi);
+                           row_hi, launch_there);
         if (rc) return fail(c, rc == 2 ? WV_ERR_INVALID : WV_ERR_HIP, "fused_prepare failed");
         if (fused_generation(c->fused) != c->elast_generation) c->elast_valid = false;
         c->elast_generation = fused_generation(c->fused);
@@ -937,12 +1027,8 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
         else if (fa && rel == sps) out = fa + 2 * c->N;
         else if (capture && s == nsteps - 2 * WV_FRAMESKIP) out = frame(c, 0);
         else if (capture && s == nsteps - WV_FRAMESKIP) out = frame(c, 1);
-        else if (s == nsteps) out = frame(c, 2);
+        else if (s == nsteps) out = other2(c);  // (never the buffer the call started from: see wv_ctx::cur2)
         else out = (cur == c->d_scratch[0]) ? c->d_scratch[1] : c->d_scratch[0];
-        if (out == cur) {  // nsteps == 1: the step would read and write the last frame
-            HIPCHK(c, hipMemcpyAsync(c->d_scratch[0], cur, c->N * sizeof(float), hipMemcpyDeviceToDevice, st));
-            cur = c->d_scratch[0];
-        }
         const Cyl *cyl_s = q.d_cyl + (size_t)(3 * (s - 1)) * (M > 0 ? M : 0);
         const float *sf = q.h_sfac + 3 * (size_t)(s - 1);
         float *ep = want_signal ? q.d_epart + (size_t)s * nblocks * 3 : nullptr;
@@ -992,17 +1078,20 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     if (impl == WV_IMPL_STAGED && !c->profiling) {
         HIPCHK(c, hipEventRecord(q.kev[1], st));  // (whole chain of stage kernels: total_ms of the call)
     } else if (impl == WV_IMPL_FUSED && !c->profiling) {
-        // the integrator launch(es) of the call between two events: for the resident path that is exactly the one kernel
-        // (the resident launch carries the two events itself: no event packets between consecutive actions)
-        if (fused_run(c->fused, si, fcall, c->fsteps.data(), (int)c->fsteps.size(), st, q.kev[0], q.kev[1]) != 0)
+        // The resident path hands the call to the resident launch as a job (which does the second pass of the energy sums
+        // itself, straight into q.h_signal, and is timed by its own clock stamps); the single-step path puts its launches
+        // between two events.
+        const FusedEnergy ef{row0, q.d_epart, want_signal ? q.h_signal : nullptr, c->dOmega};
+        if (fused_run(c->fused, si, fcall, c->fsteps.data(), (int)c->fsteps.size(), st, up, ef, may_stay, q.kev[0], q.kev[1]) != 0)
             return fail(c, WV_ERR_HIP, std::string("fused_run failed: ") + hipGetErrorString(hipGetLastError()));
-        q.bracketed = true;
         q.resident = fused_last_resident(c->fused);
+        q.bracketed = !q.resident;
         if (q.resident) q.prof_launches = 1;
     } else if (impl == WV_IMPL_FUSED) {
-        // profiling: the single resident launch bracketed by one pair of events, else every step by its own pair
+        // profiling: the resident launch (it ends with the call) bracketed by one pair of events, else every step by its own pair
         HIPCHK(c, hipEventRecord(q.kev[0], st));
-        const int rr = fused_try_resident(c->fused, si, fcall, c->fsteps.data(), (int)c->fsteps.size(), st);
+        const FusedEnergy ef{row0, q.d_epart, want_signal ? q.h_signal : nullptr, c->dOmega};
+        const int rr = fused_try_resident(c->fused, si, fcall, c->fsteps.data(), (int)c->fsteps.size(), st, up, ef, false);
         if (rr > 0) return fail(c, WV_ERR_HIP, std::string("fused_try_resident failed: ") + hipGetErrorString(hipGetLastError()));
         if (rr == 0) {
             HIPCHK(c, hipEventRecord(q.kev[1], st));
@@ -1019,19 +1108,21 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     }
     g_hostprof.lap(5);
     HIPCHK(c, hipGetLastError());
-    const int *ab_src = (impl == WV_IMPL_FUSED && q.resident) ? fused_abort_src(c->fused) : nullptr;
-    int *ab_dst = impl == WV_IMPL_FUSED ? fused_abort_dst(c->fused, si) : nullptr;
+    q.fsteps = c->fsteps;
+    q.fcall = fcall;
+    q.row0 = row0;
+    q.nblocks = nblocks;
+    // (nothing may be enqueued behind a resident launch that stays on the device: it would wait out the launch's idle limit)
+    const bool stream_free = !(impl == WV_IMPL_FUSED && fused_persist_alive(c->fused));
     if (want_signal) {
-        // second pass of the reductions, written straight into pinned host memory together with the resident kernel's
-        // give-up word: wv_integrate_end only waits for the call's last event and copies 1.2 KB host to host
-        launch_energy_final(row0, q.d_epart, nsteps + 1, nblocks, c->dOmega, q.h_signal, ab_src, ab_dst, st);
+        // second pass of the reductions (single-step and staged paths; the resident kernel has done it), written straight
+        // into pinned host memory: wv_integrate_end only waits for the call's last event and copies 1.2 KB host to host
+        if (!q.resident) launch_energy_final(row0, q.d_epart, nsteps + 1, nblocks, c->dOmega, q.h_signal, nullptr, nullptr, st);
         c->elast = q.d_epart + (size_t)nsteps * nblocks * 3;
         c->elast_blocks = nblocks;
-    } else if (ab_src) {
-        HIPCHK(c, hipMemcpyAsync(ab_dst, ab_src, sizeof(int), hipMemcpyDeviceToHost, st));
     }
     c->elast_valid = want_signal != 0;
-    HIPCHK(c, hipEventRecord(q.ev1, st));
+    if (stream_free) HIPCHK(c, hipEventRecord(q.ev1, st));
     if (streamed) {
         if (!c->down_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
         HIPCHK(c, hipStreamWaitEvent(c->down_stream, q.ev1, 0));
@@ -1041,6 +1132,14 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     }
     HIPCHK(c, hipGetLastError());
 
+    if (c->frames_exposed) {
+        // somebody holds the raw pointer of env.wave (wv_device_frames): the last frame has to stay where that pointer says,
+        // so the final state is copied home behind the call (23.5 MB at 700^2 per call, on this path only)
+        HIPCHK(c, hipMemcpyAsync(c->d_frames + 2 * c->N, c->d_f2alt, c->N * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipEventRecord(q.ev1, st));
+    } else {
+        c->cur2 ^= 1;  // env.wave[:, :, :, end] is what this call leaves behind (stream order)
+    }
     q.pending = true;
     q.capture_all = capture_all;
     if (capture_all) c->seq_frames_actions = seq_n;
@@ -1056,6 +1155,56 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     return WV_OK;
 }
 
+// The resident kernel gave up the oldest pending call `si` (and with it every call behind it: the launch has left).  Nothing has
+// been written over the initial condition (the final state goes to the other of two buffers, wv_ctx::cur2), so the very same call -- same tables, same
+// buffers -- runs again on the single-step kernels, and so does a second pending call that was meant for the same launch.
+static int rerun_after_give_up(wv_ctx *c, int si)
+{
+    hipStream_t st = c->stream;
+    fused_gave_up(c->fused, st);
+    const int order[2] = {si, (si + 1) % 2};
+    for (int k = 0; k < 2; ++k) {
+        wv_ctx::Slot &q = c->slot[order[k]];
+        if (!q.pending || !q.resident) continue;
+        if (fused_rerun_steps(c->fused, order[k], q.fcall, q.fsteps.data(), (int)q.fsteps.size(), st, q.kev[0], q.kev[1]) != 0)
+            return fail(c, WV_ERR_HIP, std::string("the single-step kernels failed after a resident give-up: ") + hipGetErrorString(hipGetLastError()));
+        if (q.want_signal) launch_energy_final(q.row0, q.d_epart, q.nsteps + 1, q.nblocks, c->dOmega, q.h_signal, nullptr, nullptr, st);
+        HIPCHK(c, hipEventRecord(q.ev1, st));
+        if (q.streamed) {  // (the copy enqueued with the call took what the abandoned launch had left there)
+            HIPCHK(c, hipStreamWaitEvent(c->down_stream, q.ev1, 0));
+            HIPCHK(c, hipMemcpyAsync(q.h_traj, q.d_traj, (size_t)2 * q.planes * c->P * sizeof(float), hipMemcpyDeviceToHost, c->down_stream));
+            HIPCHK(c, hipEventRecord(q.copy_ev, c->down_stream));
+        }
+        q.resident = false;
+        q.bracketed = true;
+        q.prof_launches = q.nsteps;
+        q.prof_events = q.nsteps;
+        q.gave_up = true;
+    }
+    return WV_OK;
+}
+
+// poll an event for a while before falling back to a blocking wait (the wake-up of a blocking wait costs more than the
+// rest of wv_integrate_end)
+static int wait_event(wv_ctx *c, hipEvent_t ev)
+{
+    static const bool spin = !(getenv("WAVES_AMD_SPIN") && atoi(getenv("WAVES_AMD_SPIN")) == 0);
+    if (spin) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t e = hipEventQuery(ev);
+            if (e == hipSuccess) return WV_OK;
+            if (e != hipErrorNotReady) {
+                (void)hipGetLastError();
+                break;
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+        }
+    }
+    HIPCHK(c, hipEventSynchronize(ev));
+    return WV_OK;
+}
+
 int wv_integrate_end(wv_ctx *c, float *signal, float *u_tot, float *u_inc)
 {
     CHECK_CTX(c);
@@ -1068,33 +1217,32 @@ int wv_integrate_end(wv_ctx *c, float *signal, float *u_tot, float *u_inc)
     const int n = q.nsteps;
     hipStream_t st = c->stream;
     const size_t tp = (size_t)q.planes * c->P;
+    double job_ms = -1.0;
+    if (q.impl == WV_IMPL_FUSED && q.resident) {
+        // the job's completion word in pinned memory (no HIP call on this path when the launch stays on the device)
+        const int jr = fused_job_wait(c->fused, si, st);
+        if (jr == 1) return fail(c, WV_ERR_HIP, std::string("waiting for the resident launch failed: ") + hipGetErrorString(hipGetLastError()));
+        if (jr == 2) {
+            const int rc = rerun_after_give_up(c, si);
+            if (rc) return rc;
+        } else {
+            job_ms = fused_last_job_ms(c->fused);
+        }
+    }
     if (u_tot && !q.streamed) HIPCHK(c, hipMemcpyAsync(u_tot, c->d_traj, tp * sizeof(float), hipMemcpyDeviceToHost, st));
     if (u_inc && !q.streamed) HIPCHK(c, hipMemcpyAsync(u_inc, c->d_traj + tp, tp * sizeof(float), hipMemcpyDeviceToHost, st));
-    if ((!u_tot && !u_inc) || q.streamed) {
-        // everything the caller gets is already on its way (or here): poll the call's last event for a while before
-        // falling back to a blocking wait (the wake-up of a blocking wait costs more than the rest of this function)
-        static const bool spin = !(getenv("WAVES_AMD_SPIN") && atoi(getenv("WAVES_AMD_SPIN")) == 0);
-        bool done = false;
-        if (spin) {
-            const auto t0 = std::chrono::steady_clock::now();
-            for (;;) {
-                const hipError_t e = hipEventQuery(q.ev1);
-                if (e == hipSuccess) {
-                    done = true;
-                    break;
-                }
-                if (e != hipErrorNotReady) {
-                    (void)hipGetLastError();
-                    break;
-                }
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
-            }
-        }
-        if (!done) HIPCHK(c, hipEventSynchronize(q.ev1));
-    } else {
+    if ((u_tot || u_inc) && !q.streamed) {
         HIPCHK(c, hipStreamSynchronize(st));
+    } else if (job_ms < 0.0) {
+        // everything the caller gets is already on its way (or here): wait for the call's last event
+        const int rc = wait_event(c, q.ev1);
+        if (rc) return rc;
     }
     if (q.streamed) HIPCHK(c, hipEventSynchronize(q.copy_ev));
+    if (c->frames_exposed && job_ms >= 0.0) {  // (the copy of the final state to where the raw pointer expects it)
+        const int rc = wait_event(c, q.ev1);
+        if (rc) return rc;
+    }
     q.pending = false;
     c->n_pending--;
     if (signal) memcpy(signal, q.h_signal, (size_t)(n + 1) * 3 * sizeof(float));
@@ -1105,18 +1253,23 @@ int wv_integrate_end(wv_ctx *c, float *signal, float *u_tot, float *u_inc)
     c->last_view_tot = q.streamed ? q.h_traj : nullptr;
     c->last_view_inc = q.streamed ? q.h_traj + tp : nullptr;
     c->last_view_planes = q.streamed ? q.planes : 0;
-    if (q.impl == WV_IMPL_FUSED && c->n_pending == 0) fused_dump_stamps(c->fused, st);
+    if (q.impl == WV_IMPL_FUSED && c->n_pending == 0 && !fused_persist_alive(c->fused)) fused_dump_stamps(c->fused, st);
     c->timing = wv_timing{};
     c->timing.steps = n;
     c->timing.impl = q.impl;
     c->timing.resident = q.resident ? 1 : 0;
-    float ms = 0.0f;
-    HIPCHK(c, hipEventElapsedTime(&ms, q.kev[0], q.ev1));
-    c->timing.total_ms = ms;  // first integrator launch -> last device work of the call
-    if (q.impl == WV_IMPL_FUSED && fused_finish(c->fused, si, st) != 0)
-        return fail(c, WV_ERR_HIP, "wv_integrate: the resident step kernel gave up waiting for a neighbouring tile "
-                                   "(device shared with another process?); the state is invalid: wv_reset / wv_set_state.  "
-                                   "This context uses the single-step kernels from now on");
+    c->timing.gave_up = q.gave_up ? 1 : 0;
+    q.gave_up = false;
+    if (q.resident && job_ms >= 0.0) {
+        // the leader tile's clock stamps: job seen -> outputs complete (in a launch that stays, HIP events see only the launch)
+        c->timing.total_ms = job_ms;
+        c->timing.step_kernel_ms = job_ms;
+        c->timing.step_kernel_launches = 1;
+    } else {
+        float ms = 0.0f;
+        HIPCHK(c, hipEventElapsedTime(&ms, q.kev[0], q.ev1));
+        c->timing.total_ms = ms;  // first integrator launch -> last device work of the call
+    }
     if (q.bracketed) {
         float k = 0.0f;
         HIPCHK(c, hipEventElapsedTime(&k, q.kev[0], q.kev[1]));
@@ -1124,6 +1277,9 @@ int wv_integrate_end(wv_ctx *c, float *signal, float *u_tot, float *u_inc)
         c->timing.step_kernel_launches = q.prof_launches;
     }
     if (c->profiling) {
+        // (a resident call is known to be complete from the kernel's own completion word, a moment before the events behind
+        // the launch have fired)
+        if (q.prof_events > 0) HIPCHK(c, hipEventSynchronize(q.kev[2 * (q.prof_events - 1) + 1]));
         double sum = 0.0;
         for (int s = 0; s < q.prof_events; ++s) {
             float k = 0.0f;
@@ -1133,6 +1289,7 @@ int wv_integrate_end(wv_ctx *c, float *signal, float *u_tot, float *u_inc)
         c->timing.step_kernel_ms = sum;
         c->timing.step_kernel_launches = q.prof_launches;
     }
+    fused_launch_stats(c->fused, &c->timing.launch_ms, &c->timing.launch_jobs);
     return WV_OK;
 }
 
@@ -1152,6 +1309,14 @@ int wv_integrate(wv_ctx *c, const float *tspan, int nsteps, int capture, float *
     int rc = wv_integrate_begin(c, tspan, nsteps, capture, signal != nullptr, (u_tot || u_inc) ? 1 : 0);
     if (rc) return rc;
     return wv_integrate_end(c, signal, u_tot, u_inc);
+}
+
+int wv_pending(wv_ctx *c, int *count)
+{
+    if (!c) return fail(nullptr, WV_ERR_INVALID, "ctx is NULL");
+    if (!count) return fail(c, WV_ERR_INVALID, "wv_pending: NULL");
+    *count = c->n_pending;
+    return WV_OK;
 }
 
 int wv_set_trajectory_stride(wv_ctx *c, int stride)
@@ -1181,6 +1346,7 @@ int wv_get_timing(wv_ctx *c, wv_timing *out)
 int wv_set_stream(wv_ctx *c, void *hip_stream)
 {
     CHECK_CTX(c);
+    QUIET(c);
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_set_stream: an integrate is pending");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
@@ -1190,6 +1356,7 @@ int wv_set_stream(wv_ctx *c, void *hip_stream)
 int wv_synchronize(wv_ctx *c)
 {
     CHECK_CTX(c);
+    QUIET(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return WV_OK;
 }
@@ -1197,7 +1364,13 @@ int wv_synchronize(wv_ctx *c)
 int wv_device_frames(wv_ctx *c, void **dptr, size_t *bytes)
 {
     CHECK_CTX(c);
+    QUIET(c);
     if (!dptr) return fail(c, WV_ERR_INVALID, "wv_device_frames: NULL");
+    if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_device_frames: an integrate is pending");
+    {
+        const int rc = frames_home(c);
+        if (rc) return rc;
+    }
     *dptr = c->d_frames;
     if (bytes) *bytes = 3 * c->N * sizeof(float);
     // the caller may write through the pointer at any time from now on: until wv_release_device_frames every integrate
@@ -1211,6 +1384,7 @@ int wv_device_frames(wv_ctx *c, void **dptr, size_t *bytes)
 int wv_release_device_frames(wv_ctx *c)
 {
     CHECK_CTX(c);
+    QUIET(c);
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_release_device_frames: an integrate is pending");
     c->frames_exposed = false;
     fused_state_changed(c->fused);  // (whatever was written before the release is looked at once more)
@@ -1221,6 +1395,7 @@ int wv_release_device_frames(wv_ctx *c)
 int wv_selftest_granules(wv_ctx *c, int iters, unsigned long long *checked, unsigned long long *torn)
 {
     CHECK_CTX(c);
+    QUIET(c);
     if (iters < 1 || !checked || !torn) return fail(c, WV_ERR_INVALID, "wv_selftest_granules: bad arguments");
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_selftest_granules: an integrate is pending");
     const unsigned bytes = 32u << 20;
@@ -1365,6 +1540,7 @@ int wv_latent_adjoint(const wv_latent_config *cfg, const float *x, const float *
 int wv_device_source_shape(wv_ctx *c, void **dptr, size_t *bytes)
 {
     CHECK_CTX(c);
+    QUIET(c);
     if (!dptr) return fail(c, WV_ERR_INVALID, "wv_device_source_shape: NULL");
     *dptr = c->d_G;
     if (bytes) *bytes = c->P * sizeof(float);

@@ -40,6 +40,7 @@ int fused_generation(const FusedPlan *p);
 // tile does not write
 bool fused_reduced(const FusedPlan *p);
 void fused_dump_stamps(FusedPlan *p, hipStream_t s);  // diagnostic, no-op unless WAVES_AMD_STAMPS is set
+// (defer_wait: a resident launch owns `s` -- nothing is enqueued there, fused_try_resident waits for the uploads itself)
 // Called once per wv_integrate before the first step: d_table = device cylinder table (rows x M), h_table its host copy.
 // frames = env.wave (3 states, the last one is the initial condition), scratch0/1 the two ping-pong states.
 // G = device source shape or nullptr (NoSource).
@@ -48,30 +49,55 @@ void fused_dump_stamps(FusedPlan *p, hipStream_t s);  // diagnostic, no-op unles
 // prepares call k+1 while call k runs), so everything a call's kernels read that differs from call to call exists twice.
 // The tile / cylinder-index tables are uploaded on `up` (a copy stream); `s` then waits for everything enqueued on `up`
 // so far, so the caller's own uploads on `up` (enqueued before this call) are covered by the same wait.
-int fused_prepare(FusedPlan *p, int slot, float *frames, float *scratch0, float *scratch1, bool capture, const float *G,
+// ic / out2: the state the call starts from and the buffer its final state goes to (one of two that alternate: out2_idx
+// says which, for the "holds zeros where reduced tiles do not write" bookkeeping).
+int fused_prepare(FusedPlan *p, int slot, float *frames, float *ic, float *out2, int out2_idx, float *scratch0, float *scratch1, bool capture, const float *G,
                   const Cyl *d_table, const Cyl *h_table, int M, int rows, hipStream_t s, hipStream_t up, int row_lo = -1,
-                  int row_hi = -1);
+                  int row_hi = -1, bool defer_wait = false);
 void fused_scratch_dirty(FusedPlan *p);  // somebody else wrote into the scratch states (wv_rhs)
 void fused_source_changed(FusedPlan *p);  // the source shape was replaced
 // one step, eagerly, as a single launch over all tiles (profiling mode brackets these with events)
 void fused_launch(FusedPlan *p, int slot, const FusedCall &call, int step, const FusedStep &st, hipStream_t s);
-// all steps of a call: one launch of the resident kernel when the tiles fit the device at once, else a cached hipGraph of
-// single-step kernel nodes (WAVES_AMD_FUSED_GRAPH=0: eager launches).  Returns 0 on success.
-int fused_run(FusedPlan *p, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s,
-              hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);  // the events bracket the integrator launch(es)
-// After the stream has been waited for: 0, or 1 when the resident kernel of the last fused_run abandoned the call (a tile
-// waited in vain for its neighbours -- the state is then invalid; the protocol has been reset).
-int fused_finish(FusedPlan *p, int slot, hipStream_t s);
+// Where the energy trace of a call goes when the resident kernel produces it (the tiles do k_energy_final's second pass
+// themselves): row0 = partial sums of the initial state [blocks][3], epart = [nsteps + 1][blocks][3] (row s = after step s),
+// signal = PINNED HOST memory [(nsteps + 1)][3] or nullptr (no trace wanted).
+struct FusedEnergy {
+    const float *row0;
+    const float *epart;
+    float *signal;
+    float dOmega;
+};
+// all steps of a call: one JOB of the resident kernel when the tiles fit the device at once (fused_body.h, "jobs": the
+// launch may outlive the call and serve the next ones), else a cached hipGraph of single-step kernel nodes
+// (WAVES_AMD_FUSED_GRAPH=0: eager launches).  `up`: the stream the call's tables were uploaded on.  keep: the resident
+// launch may stay on the device after this call.  The events bracket the single-step launches (they are not used by the
+// resident path, whose durations come from the launch's own events and the kernel's clock stamps).  Returns 0 on success.
+int fused_run(FusedPlan *p, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s, hipStream_t up,
+              const FusedEnergy &ef, bool keep, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// Resident path only.  Returns 0 when the job was handed over, -1 when this call cannot take that path (more tiles than
+// the device holds at once, a single step, ...; the caller then launches step by step), 1 on a HIP error.
+int fused_try_resident(FusedPlan *p, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s,
+                       hipStream_t up, const FusedEnergy &ef, bool keep);
+// Wait for the slot's resident call: 0 done (also when the slot has none), 2 the resident kernel gave the call up -- nothing
+// has been written over its initial condition; run it again with fused_rerun_steps after fused_gave_up --, 1 HIP error.
+int fused_job_wait(FusedPlan *p, int slot, hipStream_t s);
+void fused_gave_up(FusedPlan *p, hipStream_t s);
+int fused_rerun_steps(FusedPlan *p, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s,
+                      hipEvent_t ev_start, hipEvent_t ev_stop);
+// A resident launch is on the device waiting for (or working on) jobs: nothing may be enqueued on the context's stream
+// until fused_retire has made it leave (it would wait out the launch's idle limit).  fused_needs_stream: would preparing
+// such a call enqueue anything there?
+bool fused_persist_alive(FusedPlan *p);
+int fused_retire(FusedPlan *p);
+bool fused_needs_stream(FusedPlan *p, bool capture, const float *G, int out2_idx);
+void fused_allow_persist(FusedPlan *p, bool allow);  // per call: false ends the launch with the call
+double fused_last_job_ms(const FusedPlan *p);        // in-kernel duration of the resident call waited for last
+void fused_launch_stats(const FusedPlan *p, double *ms, int *jobs);  // HIP-event duration and jobs of the launch that ended last
 // device word the resident kernel sets when it gives up / pinned host word of this slot the caller has it copied to
 const int *fused_abort_src(const FusedPlan *p);
 int *fused_abort_dst(FusedPlan *p, int slot);
-bool fused_last_resident(const FusedPlan *p);  // the last fused_run took the single-launch path
-// All steps in one cooperative launch of k_steps_resident.  Returns 0 when launched, -1 when this call cannot take that
-// path (more tiles than the device holds at once, a single step, diagnostics ...; the caller then launches step by
-// step), 1 on a HIP error.  fused_run tries this first.
+bool fused_last_resident(const FusedPlan *p);  // the last fused_run took the resident path
 void fused_allow_resident(FusedPlan *p, bool allow);  // per call: false keeps this call on the single-step kernels
-int fused_try_resident(FusedPlan *p, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s,
-                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void fused_variant_counts(const FusedPlan *p, int out[4]);  // tiles per field set: NONE, PX, PY, ALL
 
 }  // namespace wv

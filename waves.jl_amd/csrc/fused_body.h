@@ -97,6 +97,72 @@ struct FusedParams {
     int reduced;               // the tiles use reduced field sets (auxiliary fields are zero outside the PML)
     int max_polls;             // a wave gives up (and the launch drains) after this many polls of one halo
     unsigned long long *stamps;  // diagnostic: [ntiles][16] shader-clock stamps per phase, or nullptr (normal runs)
+    // k_steps_resident as a JOB of the action-outliving launch (see "jobs" below); all zero / nullptr for k_step_fused
+    unsigned seq;              // number of this job (1, 2, ...: never 0)
+    int cmd;                   // JOB_RUN, or JOB_EXIT: the host retires the launch
+    int last;                  // the launch ends after this job (profiling, diagnostics, contexts that may not idle on the device)
+    int ntiles;                // blocks of the launch == tiles of the plan
+    // the second pass of the energy sums (k_energy_final's arithmetic, done by the tiles themselves after the job's last step)
+    const float *ef_row0;      // partial sums of the initial state [ntiles][3] (the previous job's last row, or k_energy_partial's)
+    const float *ef_epart;     // [nsteps + 1][ntiles][3]; row 0 unused
+    float *ef_signal;          // pinned HOST memory [(nsteps + 1)][3], or nullptr: no trace wanted
+    float ef_dOmega;
+    int pad2;
+    struct JobCtl *ctl;        // the launch's control block in device memory (flag arrays of the barriers)
+    struct JobBack *back;      // diagnostic (WAVES_AMD_JOBLOG): where the leader tile stamps the phases of the job, or nullptr
+};
+
+// ---- jobs: the resident launch that outlives the action ---------------------------------------------------------------
+// One launch of k_steps_resident serves a SEQUENCE of wv_integrate calls ("jobs").  The host describes job `seq` in pinned
+// memory (JobMail::desc[seq & 1]) and rings JobMail::bell = seq with plain CPU stores -- no HIP call; block 0 (the leader)
+// polls the bell, copies the description into device memory (JobCtl::jobs[seq & 1]) and releases the other blocks through
+// JobCtl::go[seq & 1].  Every block then runs the job exactly as a single launch would (its tile of THIS job: the tile
+// table, the culled cylinder lists and the launch order may differ from job to job, so the state travels through memory
+// between jobs: final-state stores of job k, the end-of-job barrier, state loads of job k + 1), joins the end-of-job
+// barrier, reduces its share of the energy-trace rows into pinned host memory and reports through JobBack.  What a job
+// saves over a launch: the start-up ramp of ~490 workgroups (38 us at 700^2), the kernel-to-kernel gap (41 us) and every
+// HIP API call on the host's path.  The launch leaves when told to (JOB_EXIT / FusedParams::last), when a tile gives up
+// (abort word), or when no bell has rung for `idle_ticks` -- it never waits unboundedly for the host.
+enum : int { JOB_RUN = 1, JOB_EXIT = 2 };
+constexpr int JOB_MAX_TILES = 2048;  // (grids of the resident kernel: at most the block slots of the device, 512 on MI355X)
+enum : unsigned { JOBS_RUNNING = 0, JOBS_EXIT_TOLD = 1, JOBS_EXIT_IDLE = 2, JOBS_EXIT_ABORT = 3, JOBS_EXIT_LAST = 4 };
+
+struct JobMail {                 // pinned host memory; written by the host, read by the leader block
+    unsigned bell;               // number of the newest job described (monotonic)
+    unsigned pad[15];
+    FusedParams desc[2];         // desc[seq & 1] describes job `seq` once bell >= seq
+};
+struct JobBack {                 // pinned host memory; written by the device
+    unsigned done;               // number of the newest job whose outputs (state, frames, trace rows) are complete
+    unsigned status;             // JOBS_*: why the launch has left (JOBS_RUNNING while it has not)
+    unsigned exit_seq;           // the job the launch was waiting for / working on when it left
+    unsigned pad[13];
+    unsigned long long t_begin[2], t_end[2];  // [seq & 1]: 100 MHz device clock when the leader saw the job / saw it complete
+    unsigned long long phase[2][8];           // diagnostic (FusedParams::back): the leader tile's clock at the phases of the job
+    unsigned rowdone[JOB_MAX_TILES];          // [block]: number of the newest job whose trace rows of this block are in host memory
+};
+struct JobGo {
+    unsigned seq, cmd;           // written as ONE 8-byte word
+};
+struct JobCtl {                  // device memory
+    JobGo go[2];                 // [seq & 1]
+    unsigned pad[12];
+    FusedParams jobs[2];         // the leader's copies of JobMail::desc
+    // followed by flag arrays of `ntiles` words each (job_flags): 0 = A "reached the end of the last step" (nobody has given
+    // up: the final state may now replace the initial condition), 1 = B "all stores of the job have left"
+};
+WV_HD unsigned *job_flags(JobCtl *c, int which, int ntiles) { return reinterpret_cast<unsigned *>(c + 1) + (size_t)which * (size_t)((ntiles + 63) & ~63); }
+constexpr size_t job_ctl_bytes(int ntiles) { return sizeof(JobCtl) + 2 * (size_t)((ntiles + 63) & ~63) * sizeof(unsigned); }
+
+// kernel arguments of k_steps_resident
+struct JobArgs {
+    const JobMail *mail;
+    JobBack *back;
+    JobCtl *ctl;
+    unsigned first_seq;          // the first job this launch serves
+    unsigned idle_ticks;         // the leader leaves after this many 100 MHz ticks without a new bell
+    int ntiles;
+    int pad;
 };
 
 // LDS image of one tile, carved out of one raw buffer (the kernel instantiates field sets with different RY over the
@@ -1038,6 +1104,152 @@ WV_HD void fused_store(const FusedParams &p, const StepIO &io, const TileDesc &t
         if (io_tt) io_tt[id] = ut;
         if (io_ti) io_ti[id] = ui;
     }
+}
+
+// ---- job protocol primitives (device: one WAVE executes them, lanes in parallel; CPU emulation: one thread, lane == 0) ----
+// Scopes: "agent" = other blocks of the launch (sc1: served from L2 / memory, never from a CU's L1), "sys" = the host.
+#if defined(__HIPCC__)
+#define WV_SCOPE_AGENT __HIP_MEMORY_SCOPE_AGENT
+#define WV_SCOPE_SYS __HIP_MEMORY_SCOPE_SYSTEM
+#else
+#define WV_SCOPE_AGENT 0
+#define WV_SCOPE_SYS 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WV_JOB_LD(p, scope) __hip_atomic_load(p, __ATOMIC_RELAXED, scope)
+#define WV_JOB_ST(p, v, scope) __hip_atomic_store(p, v, __ATOMIC_RELAXED, scope)
+constexpr int JOB_LANES = 64;
+#else
+#define WV_JOB_LD(p, scope) __atomic_load_n(p, __ATOMIC_ACQUIRE)
+#define WV_JOB_ST(p, v, scope) __atomic_store_n(p, v, __ATOMIC_RELEASE)
+constexpr int JOB_LANES = 1;
+unsigned long long emu_job_clock();  // provided by the CPU emulation (a virtual clock it can move at will) ...
+void emu_job_pause();                // ... and its yield to the other emulated blocks; never referenced by the library itself
+#endif
+WV_HD unsigned job_ld_agent(const unsigned *p) { return WV_JOB_LD(p, WV_SCOPE_AGENT); }
+WV_HD void job_st_agent(unsigned *p, unsigned v) { WV_JOB_ST(p, v, WV_SCOPE_AGENT); }
+WV_HD unsigned long long job_ld_agent64(const unsigned long long *p) { return WV_JOB_LD(p, WV_SCOPE_AGENT); }
+WV_HD void job_st_agent64(unsigned long long *p, unsigned long long v) { WV_JOB_ST(p, v, WV_SCOPE_AGENT); }
+WV_HD unsigned job_ld_sys(const unsigned *p) { return WV_JOB_LD(p, WV_SCOPE_SYS); }
+WV_HD void job_st_sys(unsigned *p, unsigned v) { WV_JOB_ST(p, v, WV_SCOPE_SYS); }
+WV_HD void job_st_sys64(unsigned long long *p, unsigned long long v) { WV_JOB_ST(p, v, WV_SCOPE_SYS); }
+WV_HD void job_st_sysf(float *p, float v) { WV_JOB_ST(reinterpret_cast<unsigned *>(p), __builtin_bit_cast(unsigned, v), WV_SCOPE_SYS); }
+WV_HD float job_ld_agentf(const float *p) { return __builtin_bit_cast(float, WV_JOB_LD(reinterpret_cast<const unsigned *>(p), WV_SCOPE_AGENT)); }
+WV_HD void job_st_agentf(float *p, float v) { WV_JOB_ST(reinterpret_cast<unsigned *>(p), __builtin_bit_cast(unsigned, v), WV_SCOPE_AGENT); }
+WV_HD unsigned long long job_clock()  // 100 MHz
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_s_memrealtime();
+#else
+    return emu_job_clock();
+#endif
+}
+WV_HD void job_drain()  // my stores have left / my loads are back
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+WV_HD void job_pause()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_s_sleep(4);
+#else
+    emu_job_pause();
+#endif
+}
+WV_HD bool job_all(bool v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __all(v) != 0;
+#else
+    return v;
+#endif
+}
+WV_HD bool job_any(bool v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __any(v) != 0;
+#else
+    return v;
+#endif
+}
+WV_HD bool job_reached(unsigned have, unsigned want) { return (int)(have - want) >= 0; }  // (numbers wrap; launches do not live 2^31 jobs)
+
+// Leader, one wave, non-blocking: if job `seq` has been rung, bring its description over and release the other blocks
+// (they look at go[seq & 1] only once they are through with job seq - 1, so this may happen while that job still runs).
+// Returns the job's command, or 0 when nothing has been rung yet.
+WV_HD int job_try_fetch(const JobArgs &a, unsigned seq, int lane)
+{
+    const unsigned par = seq & 1u;
+    if (!job_reached(job_ld_sys(&a.mail->bell), seq)) return 0;
+    // the description, dword by dword: host memory -> device memory (sizeof(FusedParams) / 4 <= a few loads per lane)
+    const unsigned *src = reinterpret_cast<const unsigned *>(&a.mail->desc[par]);
+    unsigned *dst = reinterpret_cast<unsigned *>(&a.ctl->jobs[par]);
+    constexpr int NW4 = (int)(sizeof(FusedParams) / 4);
+    for (int k = lane; k < NW4; k += JOB_LANES) job_st_agent(dst + k, job_ld_sys(src + k));
+    job_drain();
+    const unsigned got = job_ld_agent(&a.ctl->jobs[par].seq);  // (a description that is not the one rung: treat as "leave")
+    const int cmd = (got == seq && job_ld_agent(reinterpret_cast<const unsigned *>(&a.ctl->jobs[par].cmd)) == (unsigned)JOB_RUN) ? JOB_RUN : JOB_EXIT;
+    if (lane == 0) {
+        if (cmd != JOB_RUN) {
+            job_st_sys(&a.back->exit_seq, seq);
+            job_st_sys(&a.back->status, JOBS_EXIT_TOLD);
+            job_drain();
+        }
+        job_st_agent64(reinterpret_cast<unsigned long long *>(&a.ctl->go[par]), (unsigned long long)seq | ((unsigned long long)(unsigned)cmd << 32));
+    }
+    return cmd;
+}
+
+// Leader, one wave: wait for job `seq` (bounded by idle_ticks: then back->status says JOBS_EXIT_IDLE, the others are told
+// to leave, and the host must not count on this launch for the job).  Returns the job's command.
+WV_HD int job_leader_fetch(const JobArgs &a, unsigned seq, int lane)
+{
+    const unsigned long long t0 = job_clock();
+    for (;;) {
+        const int cmd = job_try_fetch(a, seq, lane);
+        if (cmd != 0) return cmd;
+        if (job_clock() - t0 > (unsigned long long)a.idle_ticks) break;
+        job_pause();
+    }
+    if (lane == 0) {
+        job_st_sys(&a.back->exit_seq, seq);
+        job_st_sys(&a.back->status, JOBS_EXIT_IDLE);
+        job_drain();
+        job_st_agent64(reinterpret_cast<unsigned long long *>(&a.ctl->go[seq & 1u]), (unsigned long long)seq | ((unsigned long long)(unsigned)JOB_EXIT << 32));
+    }
+    return JOB_EXIT;
+}
+
+// Everybody (one wave per block): the command of job `seq`.  Bounded: a leader that never answers (it cannot: it leaves
+// through the same word) is treated as "leave".
+WV_HD int job_wait_go(const JobArgs &a, unsigned seq)
+{
+    const unsigned par = seq & 1u;
+    const unsigned long long t0 = job_clock();
+    for (;;) {
+        const unsigned long long g = job_ld_agent64(reinterpret_cast<const unsigned long long *>(&a.ctl->go[par]));
+        if ((unsigned)g == seq) return (int)(unsigned)(g >> 32);
+        if (job_clock() - t0 > 16ull * (unsigned long long)a.idle_ticks + 100000ull) return JOB_EXIT;
+        job_pause();
+    }
+}
+
+// Grid barrier through a flag array: flags[b] = seq says "block b has arrived"; returns when every block has (true), or when
+// the abort word is set / max_polls looks did not suffice (false).  One wave; the caller has made sure (barrier + drain)
+// that what the arrival stands for has happened in EVERY wave of the block.
+WV_HD bool job_barrier(unsigned *flags, int ntiles, int b, unsigned seq, int max_polls, int *abort, int lane)
+{
+    if (lane == 0) job_st_agent(flags + b, seq);
+    for (int polls = 0; polls < max_polls; ++polls) {
+        bool ok = true;
+        for (int k = lane; k < ntiles; k += JOB_LANES) ok = ok && job_reached(job_ld_agent(flags + k), seq);
+        if (job_all(ok)) return true;
+        if (job_any(job_ld_agent(reinterpret_cast<const unsigned *>(abort)) != 0u)) return false;
+        job_pause();
+    }
+    return false;
 }
 
 }  // namespace wv

@@ -39,6 +39,15 @@ __device__ __forceinline__ int opaque(int v)
     return v;
 }
 
+// a pointer / number that IS the same in every lane, said so to the compiler (it then lives in scalar registers)
+template <class T>
+__device__ __forceinline__ T *uniform_ptr(T *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
+
 // The tile descriptor of this block, through scalar loads (the table is written by the host before the launch and by
 // nobody during it; left to itself the compiler fetches it with vector loads -- a memory round trip in front of everything)
 __device__ __forceinline__ TileDesc load_tile(const FusedParams &p)
@@ -178,9 +187,29 @@ constexpr int WV_WAIT_POLLS = 1 << 20;  // default of FusedParams::max_polls (WA
 // barrier that orders LDS accesses only (__syncthreads also waits for every outstanding global access)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// One JOB of one tile.  Returns false when the job was abandoned (a wave of this or of another block gave up waiting: the
+// abort word is set and every block leaves); the job's initial condition is never written (its final state has a buffer of
+// its own).
+// NOT inlined into the job loop of the kernel (WV_TILE_CALL): as part of that loop's body the very same instructions of a
+// step ran 3.5 % slower (the step loop then is a loop inside a loop with seventeen bodies: layout and allocation are shaped
+// around all of them); as a function of its own each variant is laid out and allocated like the one-job kernel of round 2.
+// The LDS arrays travel as address-space-3 pointers so that their accesses stay ds_ instructions, the job description as a
+// pointer that is made uniform again on this side of the call (arguments travel in vector registers).
+#ifndef WV_TILE_INLINE
+#define WV_TILE_CALL __attribute__((noinline))
+#else
+#define WV_TILE_CALL __forceinline__
+#endif
+typedef __attribute__((address_space(3))) F2 *lds_f2_ptr;
+typedef __attribute__((address_space(3))) float *lds_f_ptr;
+typedef __attribute__((address_space(3))) int *lds_i_ptr;
 template <int AUX, int FL, int NW, int RPT, int RYMAX>
-__device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw, float (*red)[NW], int *vote)
+__device__ WV_TILE_CALL bool run_tile_resident(const FusedParams *p0_, lds_f2_ptr raw_, lds_f_ptr red_, lds_i_ptr vote_)
 {
+    const FusedParams *p0 = uniform_ptr(p0_);
+    F2 *raw = (F2 *)raw_;
+    float(*red)[NW] = (float(*)[NW])(float *)red_;
+    int *vote = (int *)vote_;
     const FusedLds lds = lds_view(raw, NW * RPT, RYMAX);
     FusedRegs<AUX, RPT> r;
     TileCtx cx;
@@ -191,7 +220,7 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
     if (AUX == AUX_NONE) __builtin_amdgcn_s_setprio(2);
 #endif
     // the tile descriptor once, in scalar registers: a scalar load chain at the top of every step costs 1.3 %
-    const TileDesc t = load_tile(*p0);
+    const TileDesc t = load_tile(*opaque(p0));
 #ifndef WV_TID_SPILLED  // (the first version, kept for A/B)
     // The thread index of a step is put together from the wave's index (a scalar) and the lane number: threadIdx.x itself,
     // live around the step loop, was kept in scratch and reloaded -- with a full wait -- at the top of every step.
@@ -207,6 +236,10 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
         fused_cyl_commit<FL>(t, tid, lds, cx, fused_cyl_fetch<AUX, FL, RPT>(p, 0, t, tid, cx, r));  // steps[s].step == s
         fused_load_state<AUX, NW, RPT>(p, opaque(p.steps)[0].u, t, tid, r);
         if (tid == 0) *vote = 0;  // (set by a wave that gives up; read after the first barrier of a step)
+        if (p.back && blockIdx.x == 0 && tid == 0) {  // diagnostic
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            job_st_sys64(&p.back->phase[p.seq & 1u][1], job_clock());
+        }
     }
     for (int s = 0;; ++s) {
         const FusedParams &p = *opaque(p0);
@@ -234,9 +267,13 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
                 float v = 0.0f;
 #pragma unroll
                 for (int k = 0; k < NW; ++k) v += red[tid][k];
+#ifdef WV_PLAIN_EPART  // (timing experiment only)
                 ep[(size_t)t.slot * 3 + tid] = v;
+#else
+                job_st_agentf(ep + (size_t)t.slot * 3 + tid, v);  // (write-through: the rows are summed by other blocks of this launch)
+#endif
             }
-            if (*vote != 0) return;  // block-uniform: a block that gives up leaves together
+            if (*vote != 0) return false;  // block-uniform: a block that gives up leaves together
         }
         fused_speed<AUX, FL, NW, RPT>(p, t, tid, lds, cx, r);
         WV_STAMP(8)
@@ -257,9 +294,12 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
         if (AUX == WV_SLEEP_CLASS)
             __builtin_amdgcn_s_sleep(WV_SLEEP_LEN);
 #endif
+        // The last step ends behind the loop (what happens there -- the job's final stores, its stamps -- is then not part of the
+        // loop the register allocator and the scheduler shape around: with such code inside, the steps themselves were 2 % slower).
+        if (s + 1 == p.nsteps) break;
         // the border first: the neighbours are waiting for it
         const unsigned tag = p.tag_base + (unsigned)(s + 1);
-        if (s + 1 != p.nsteps) fused_xch_store<AUX, NW, RPT>(p, tag, t, tid, r);
+        fused_xch_store<AUX, NW, RPT>(p, tag, t, tid, r);
         float e[3];
         fused_store<AUX, NW, RPT>(p, io, t, tid, r, e);
         fused_end_step<AUX, RPT>(r);
@@ -275,16 +315,6 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
         }
 #endif
         WV_STAMP(3)
-        if (s + 1 == p.nsteps) {  // the last step closes itself
-            lds_barrier();
-            if (io.epart && tid < 3) {
-                float v = 0.0f;
-#pragma unroll
-                for (int k = 0; k < NW; ++k) v += red[tid][k];
-                io.epart[(size_t)t.slot * 3 + tid] = v;
-            }
-            return;
-        }
         // halo of the next step: every wave polls the words of its own rows
         // (the next step's cylinders travel while the halo is awaited)
         const Cyl nc = fused_cyl_fetch<AUX, FL, RPT>(p, io.step + 1, t, tid, cx, r);
@@ -340,53 +370,222 @@ __device__ __forceinline__ void run_tile_resident(const FusedParams *p0, F2 *raw
             st[13] = (unsigned long long)(t.aux | (t.edge << 4));
         }
 #undef WV_STAMP
-#undef WV_TID
     }
+    // ---- the end of the last step: stage 4 has run, the new state is in r.y
+    {
+        const FusedParams &p = *opaque(p0);
+        const int tid = opaque(WV_TID());
+        const StepIO &io = opaque(p.steps)[p.nsteps - 1];
+        if (p.back && blockIdx.x == 0 && tid == 0) job_st_sys64(&p.back->phase[p.seq & 1u][2], job_clock());  // diagnostic
+        // (No barrier in front of this store: the final state goes to a buffer of its own -- wv_ctx::cur2 --, never over the
+        // state the job started from.  A job that is given up therefore leaves its initial condition intact, and the host
+        // runs the same call again with the single-step kernels.)
+        if (p.back && blockIdx.x == 0 && tid == 0) job_st_sys64(&p.back->phase[p.seq & 1u][3], job_clock());  // diagnostic
+        float e[3];
+        fused_store<AUX, NW, RPT>(p, io, t, tid, r, e);
+#ifndef WV_NO_ENERGY  // (timing experiment only)
+        if (io.epart) {  // block-uniform
+            const int lane = tid & 63, w = wv_wave_of(tid);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = wave_sum(e[c]);
+                if (lane == 0) red[c][w] = v;
+            }
+        }
+#endif
+        lds_barrier();
+        if (io.epart && tid < 3) {
+            float v = 0.0f;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) v += red[tid][k];
+            job_st_agentf(io.epart + (size_t)t.slot * 3 + tid, v);
+        }
+    }
+#undef WV_TID
+    return true;
+}
+
+// Second pass of the energy sums of one saved time, by one block: exactly k_energy_final's arithmetic (256 threads, strided
+// double sums in a fixed order, a pairwise tree in LDS, one rounding, then * dOmega in fp32), so that the trace does not depend
+// on which kernel produced it.  The partial sums were written write-through by all blocks (barrier B lies in between).
+__device__ __forceinline__ void job_energy_row(const FusedParams &p, int row, double *red /* LDS [3][256] */)
+{
+    const int tid = (int)threadIdx.x;
+    const float *src = row == 0 ? p.ef_row0 : p.ef_epart + (size_t)row * (size_t)p.ntiles * 3;
+    if (tid < 256) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        for (int b = tid; b < p.ntiles; b += 256) {
+            s0 += (double)job_ld_agentf(src + b * 3 + 0);
+            s1 += (double)job_ld_agentf(src + b * 3 + 1);
+            s2 += (double)job_ld_agentf(src + b * 3 + 2);
+        }
+        red[tid] = s0;
+        red[256 + tid] = s1;
+        red[512 + tid] = s2;
+    }
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) red[c * 256 + tid] += red[c * 256 + tid + off];
+        }
+        __syncthreads();
+    }
+    if (tid < 3) job_st_sysf(p.ef_signal + (size_t)row * 3 + tid, (float)red[tid * 256] * p.ef_dOmega);
+    __syncthreads();  // (red is reused by the block's next row)
 }
 
 template <int NW, int RF, int RB, int RP>
-__global__ __launch_bounds__(NW * 64, 4) void k_steps_resident(FusedParams p_)
+__global__ __launch_bounds__(NW * 64, 4) void k_steps_resident(JobArgs a_)
 {
+    // The arguments are read where they are used, straight from the kernarg segment, through pointers the optimiser cannot
+    // see through: whatever is loop-invariant here (mailbox addresses, flag arrays, ...) would otherwise be hoisted out of the
+    // job loop and kept in scalar registers across the tile bodies, which have none to spare.
 #if defined(__HIP_DEVICE_COMPILE__)
-    (void)p_;
-    const FusedParams &p = *(const FusedParams *)(const void *)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)a_;
+    const JobArgs *const a0 = (const JobArgs *)(const void *)__builtin_amdgcn_kernarg_segment_ptr();
 #else
-    const FusedParams &p = p_;
+    const JobArgs *const a0 = &a_;
 #endif
     constexpr int RMAX = RF > RB ? (RF > RP ? RF : RP) : (RB > RP ? RB : RP);
     constexpr int RYMAX = NW * RMAX;
     __shared__ F2 raw[lds_elems(RYMAX)];
     __shared__ float red[3][NW];
     __shared__ int vote[1];  // a wave of the block gave up waiting for its halo
-    const TileDesc t = load_tile(p);
-#define RUN(A, F, R) run_tile_resident<A, F, NW, R, RYMAX>(&p, raw, red, vote)
-    const int fl = tile_flags(p, t);
-    const int fe = fl & F_EDGE;
-    const bool cyl = (fl & F_CYL) != 0;
-    if (t.aux == AUX_NONE) {
-        if (fl == 0) RUN(AUX_NONE, 0, RF);
-        else if (fl == F_SRC) RUN(AUX_NONE, F_SRC, RF);
-        else RUN(AUX_NONE, F_CYL | F_SRC, RF);
-    } else if (t.aux == AUX_PX) {
-        const bool src = (fl & F_SRC) != 0;
-        if (!cyl && !src && (fe & ~F_EL) == 0) RUN(AUX_PX, F_EL, RB);
-        else if (!cyl && !src && (fe & ~F_ER) == 0) RUN(AUX_PX, F_ER, RB);
-        else if (!cyl && (fe & ~F_EL) == 0) RUN(AUX_PX, F_EL | F_SRC, RB);
-        else if (!cyl && (fe & ~F_ER) == 0) RUN(AUX_PX, F_ER | F_SRC, RB);
-        else RUN(AUX_PX, F_ALL, RB);
-    } else if (t.aux == AUX_PY) {
-        if (fl == 0) RUN(AUX_PY, 0, RB);
-        else if (!cyl && (fl & F_SRC) == 0 && (fe & ~F_ET) == 0) RUN(AUX_PY, F_ET, RB);
-        else if (!cyl && (fl & F_SRC) == 0 && (fe & ~F_EB) == 0) RUN(AUX_PY, F_EB, RB);
-        else if (!cyl && (fe & ~F_ET) == 0) RUN(AUX_PY, F_ET | F_SRC, RB);
-        else if (!cyl && (fe & ~F_EB) == 0) RUN(AUX_PY, F_EB | F_SRC, RB);
-        else RUN(AUX_PY, F_ALL, RB);
-    } else {
-        if (!cyl && (fl & F_SRC) == 0) RUN(AUX_ALL, F_EDGE, RP);
-        else if (!cyl) RUN(AUX_ALL, F_EDGE | F_SRC, RP);
-        else RUN(AUX_ALL, F_ALL, RP);
+    __shared__ unsigned s_job[4];  // the job's command and number (kept here, not in registers, across the tile body); leader
+                                   // block: number and command of a job it has fetched ahead (0: none)
+    static_assert(sizeof(double) * 3 * 256 <= sizeof(F2) * lds_elems(RYMAX), "the energy rows are summed in the tile's LDS image");
+    if (threadIdx.x == 0) {
+        s_job[1] = opaque(a0)->first_seq;
+        s_job[2] = 0;
     }
+    __syncthreads();
+    for (;;) {
+        // ---- the job: block 0 asks the host, everybody else asks block 0
+        if (threadIdx.x < 64) {
+            const JobArgs &a = *opaque(a0);
+            const unsigned seq = __builtin_amdgcn_readfirstlane(s_job[1]);
+            int cmd;
+            if (blockIdx.x == 0) {
+                cmd = s_job[2] == seq ? (int)s_job[3] : job_leader_fetch(a, seq, (int)threadIdx.x);  // (fetched ahead: see below)
+                if (cmd == JOB_RUN && threadIdx.x == 0) job_st_sys64(&a.back->t_begin[seq & 1u], job_clock());
+            } else {
+                cmd = job_wait_go(a, seq);
+            }
+            // what the job reads was written while this launch was running (the leader's copy of the description, the host's
+            // uploads, other blocks' final state of the previous job): nothing of it may come from this CU's vector L1 or
+            // from the scalar cache
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __builtin_amdgcn_s_dcache_inv();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (threadIdx.x == 0) s_job[0] = (unsigned)cmd;
+        }
+        __syncthreads();
+        if (s_job[0] != (unsigned)JOB_RUN) return;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {  // diagnostic
+            const JobArgs &a = *opaque(a0);
+            const unsigned sq = s_job[1];
+            if (a.ctl->jobs[sq & 1u].back) job_st_sys64(&a.back->phase[sq & 1u][0], job_clock());
+        }
+        bool ok = true;
+        {
+            const FusedParams *pj = uniform_ptr(&opaque(a0)->ctl->jobs[__builtin_amdgcn_readfirstlane(s_job[1]) & 1u]);
+            const FusedParams &p = *opaque(pj);
+            const TileDesc t = load_tile(p);
+#define RUN(A, F, R) ok = run_tile_resident<A, F, NW, R, RYMAX>(pj, (lds_f2_ptr)raw, (lds_f_ptr)&red[0][0], (lds_i_ptr)vote)
+            const int fl = tile_flags(p, t);
+            const int fe = fl & F_EDGE;
+            const bool cyl = (fl & F_CYL) != 0;
+            if (t.aux == AUX_NONE) {
+                if (fl == 0) RUN(AUX_NONE, 0, RF);
+                else if (fl == F_SRC) RUN(AUX_NONE, F_SRC, RF);
+                else RUN(AUX_NONE, F_CYL | F_SRC, RF);
+            } else if (t.aux == AUX_PX) {
+                const bool src = (fl & F_SRC) != 0;
+                if (!cyl && !src && (fe & ~F_EL) == 0) RUN(AUX_PX, F_EL, RB);
+                else if (!cyl && !src && (fe & ~F_ER) == 0) RUN(AUX_PX, F_ER, RB);
+                else if (!cyl && (fe & ~F_EL) == 0) RUN(AUX_PX, F_EL | F_SRC, RB);
+                else if (!cyl && (fe & ~F_ER) == 0) RUN(AUX_PX, F_ER | F_SRC, RB);
+                else RUN(AUX_PX, F_ALL, RB);
+            } else if (t.aux == AUX_PY) {
+                if (fl == 0) RUN(AUX_PY, 0, RB);
+                else if (!cyl && (fl & F_SRC) == 0 && (fe & ~F_ET) == 0) RUN(AUX_PY, F_ET, RB);
+                else if (!cyl && (fl & F_SRC) == 0 && (fe & ~F_EB) == 0) RUN(AUX_PY, F_EB, RB);
+                else if (!cyl && (fe & ~F_ET) == 0) RUN(AUX_PY, F_ET | F_SRC, RB);
+                else if (!cyl && (fe & ~F_EB) == 0) RUN(AUX_PY, F_EB | F_SRC, RB);
+                else RUN(AUX_PY, F_ALL, RB);
+            } else {
+                if (!cyl && (fl & F_SRC) == 0) RUN(AUX_ALL, F_EDGE, RP);
+                else if (!cyl) RUN(AUX_ALL, F_EDGE | F_SRC, RP);
+                else RUN(AUX_ALL, F_ALL, RP);
+            }
 #undef RUN
+        }
+        // ---- the end of the job (everything re-read: nothing is carried in registers across the tile body)
+        const JobArgs &a = *opaque(a0);
+        const unsigned seq = __builtin_amdgcn_readfirstlane(s_job[1]);
+        const FusedParams &p = *opaque(uniform_ptr(&a.ctl->jobs[seq & 1u]));
+        const int b = (int)blockIdx.x;
+        if (!ok) {  // abandoned (block-uniform): tell the host why the launch is gone
+            if (threadIdx.x == 0) {
+                job_st_sys(&a.back->exit_seq, seq);
+                job_st_sys(&a.back->status, JOBS_EXIT_ABORT);
+            }
+            return;
+        }
+        // barrier B: every store of the job (final state, frames, trajectories, partial sums) of every block has left
+        job_drain();
+        __syncthreads();
+        if (p.back && b == 0 && threadIdx.x == 0) job_st_sys64(&p.back->phase[seq & 1u][4], job_clock());  // diagnostic
+        // The leader block looks for the NEXT job while its first wave waits at barrier B (the second wave has nothing else to
+        // do): the description's trip over PCIe (3 round trips, ~5 us) then lies under this job's end instead of between two jobs.
+        if (b == 0 && threadIdx.x >= 64 && threadIdx.x < 128 && !p.last) {
+            const int cmd = job_try_fetch(a, seq + 1u, (int)threadIdx.x - 64);
+            if (threadIdx.x == 64) {
+                s_job[2] = cmd != 0 ? seq + 1u : 0u;
+                s_job[3] = (unsigned)cmd;
+            }
+        }
+        if (threadIdx.x < 64) {
+            const bool okb = job_barrier(job_flags(a.ctl, 1, p.ntiles), p.ntiles, b, seq, p.max_polls, p.abort, (int)threadIdx.x);
+            if (threadIdx.x == 0) vote[0] = okb ? 0 : 1;
+        }
+        __syncthreads();
+        if (vote[0] != 0) {  // (cannot happen short of a fault: a block that got here has nothing left to wait for but the others' last stores)
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(p.abort, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                job_st_sys(&a.back->exit_seq, seq);
+                job_st_sys(&a.back->status, JOBS_EXIT_ABORT);
+            }
+            return;
+        }
+        if (p.back && b == 0 && threadIdx.x == 0) job_st_sys64(&p.back->phase[seq & 1u][5], job_clock());  // diagnostic
+        // the energy trace: block b sums the rows b, b + ntiles, ... straight into pinned host memory
+        const int nrows = p.ef_signal ? p.nsteps + 1 : 0;
+        for (int row = b; row < nrows; row += p.ntiles) job_energy_row(p, row, reinterpret_cast<double *>(raw));
+        if (b < nrows) {  // my rows are in host memory (the host looks at these words, nobody on the device waits for them)
+            job_drain();
+            __syncthreads();
+            if (threadIdx.x == 0) job_st_sys(&a.back->rowdone[b], seq);
+        }
+        // the leader reports: state, frames and trajectories of the job are complete (barrier B)
+        if (b == 0 && threadIdx.x == 0) {
+            job_st_sys64(&a.back->t_end[seq & 1u], job_clock());
+            if (p.last) {
+                job_st_sys(&a.back->exit_seq, seq);
+                job_st_sys(&a.back->status, JOBS_EXIT_LAST);
+            }
+            job_drain();
+            job_st_sys(&a.back->done, seq);
+            job_drain();
+        }
+        if (p.last) return;
+#ifdef WV_ONE_JOB  // (timing experiment only: no loop around the tile bodies)
+        return;
+#endif
+        if (threadIdx.x == 0) s_job[1] = seq + 1;
+        __syncthreads();
+    }
 }
 
 // Does the state violate "Psi_x = 0 wherever sigma_x = 0, Psi_y = 0 wherever sigma_y = 0, Omega = 0 wherever
@@ -455,7 +654,8 @@ struct FusedPlan {
     bool tiles_aux_zero = false;  // the aux_zero value the current tile classification was built with
     int aux_state = 1;            // initial condition: 1 zero outside the PML, 0 not, -1 unknown
     bool scratch_clean = true;    // the two scratch states have zero auxiliary planes outside the PML
-    bool frames_clean = true;     // ... and so have frames 0 and 1 (frame 2 is the initial condition itself)
+    bool frames_clean = true;     // ... and so have frames 0 and 1 ...
+    bool f2_clean[2] = {true, true};  // ... and the two buffers the last frame alternates between
     std::vector<int> idx;
     // per-call tables, one set per slot (two calls may be in flight): device copies and pinned staging
     int cur = 0;                  // slot of the call being prepared / launched
@@ -493,6 +693,30 @@ struct FusedPlan {
     int *h_abort = nullptr;       // pinned copies [2] (one per slot), valid after the call's last event
     bool abort_pending[2] = {false, false};  // a resident launch is in flight (or finished) whose verdict has not been looked at
     bool last_resident = false;   // the last fused_run took the single-launch path
+    // the action-outliving launch (fused_body.h, "jobs")
+    bool persist = true;          // WAVES_AMD_PERSIST=0: every resident launch ends with its job
+    bool allow_persist = true;    // set per call by the owner (profiling, caller-owned streams, shared devices: false)
+    unsigned idle_us = 1000;      // WAVES_AMD_IDLE_US: the launch leaves after this long without a new job
+    JobMail *mail = nullptr;      // pinned host memory
+    JobBack *back = nullptr;      // pinned host memory
+    JobCtl *d_ctl = nullptr;
+    int ctl_tiles = 0;            // tiles the flag arrays behind d_ctl were sized for
+    unsigned seq = 0;             // jobs described so far (job numbers start at 1)
+    bool p_alive = false;         // a launch was started and has not been waited for
+    bool p_stays = false;         // ... and the newest job it was given lets it stay (FusedParams::last == 0)
+    int p_ntiles = 0;             // its grid
+    unsigned p_first = 0;         // the first job it serves
+    hipStream_t p_stream = nullptr;
+    hipEvent_t p_start = nullptr, p_stop = nullptr, p_up = nullptr;
+    int job_rows[2] = {0, 0};         // per slot: blocks of that call that write trace rows to host memory
+    unsigned job_seq[2] = {0, 0};     // per slot: the job of the slot's resident call that has not been waited for (0: none)
+    bool job_keep[2] = {false, false};  // ... and whether the launch was asked to stay after it
+    double last_job_ms = 0.0;     // in-kernel duration of the job waited for last
+    double last_launch_ms = 0.0;  // duration (HIP events) and jobs of the launch retired last
+    int last_launch_jobs = 0;
+    unsigned p_jobs_done_at_launch = 0;
+    long n_launches = 0, n_jobs = 0, n_handed = 0;  // diagnostics (WAVES_AMD_HOSTPROF): launches, jobs, jobs handed to a launch that was there
+    std::vector<double> job_ms;   // in-kernel duration of the jobs waited for since the last fused_job_stats reset
 };
 
 FusedPlan *fused_create(const Grid &g, const float *x, const float *y, const float *sx, const float *sy)
@@ -521,6 +745,9 @@ FusedPlan *fused_create(const Grid &g, const float *x, const float *y, const flo
     if (const char *e = getenv("WAVES_AMD_FUSED_GRAPH")) p->use_graph = atoi(e) != 0;
     if (const char *e = getenv("WAVES_AMD_FUSED_RESIDENT")) p->use_resident = atoi(e) != 0;
     if (const char *e = getenv("WAVES_AMD_TAG_BASE")) p->tag_base_init = (unsigned)strtoul(e, nullptr, 0);  // tests: wrap
+    if (const char *e = getenv("WAVES_AMD_PERSIST")) p->persist = atoi(e) != 0;
+    if (const char *e = getenv("WAVES_AMD_IDLE_US")) p->idle_us = (unsigned)std::max(0, atoi(e));
+    if (p->idle_us == 0) p->persist = false;
     if (hipMalloc((void **)&p->d_flag, sizeof(int)) != hipSuccess || hipMalloc((void **)&p->d_abort, 4 * sizeof(int)) != hipSuccess ||
         hipHostMalloc((void **)&p->h_abort, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&p->up_ev[0], hipEventDisableTiming) != hipSuccess ||
@@ -536,6 +763,15 @@ FusedPlan *fused_create(const Grid &g, const float *x, const float *y, const flo
 void fused_destroy(FusedPlan *p)
 {
     if (!p) return;
+    (void)fused_retire(p);
+    if (getenv("WAVES_AMD_HOSTPROF") && p->n_jobs)
+        fprintf(stderr, "[waves_amd hostprof] resident launches %ld, jobs %ld, of them handed to a launch that was waiting: %ld\n",
+                p->n_launches, p->n_jobs, p->n_handed);
+    if (p->mail) (void)hipHostFree(p->mail);
+    if (p->back) (void)hipHostFree(p->back);
+    if (p->d_ctl) (void)hipFree(p->d_ctl);
+    for (hipEvent_t e : {p->p_start, p->p_stop, p->p_up})
+        if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < 2; ++k) {
         if (p->d_tiles[k]) (void)hipFree(p->d_tiles[k]);
         if (p->h_tiles[k]) (void)hipHostFree(p->h_tiles[k]);
@@ -563,18 +799,21 @@ void fused_set_pml(FusedPlan *p, const float *sx, const float *sy)
     p->aux_state = -1;
     p->scratch_clean = false;
     p->frames_clean = false;
+    p->f2_clean[0] = p->f2_clean[1] = false;
 }
 
 void fused_state_changed(FusedPlan *p)
 {
     p->aux_state = -1;
     p->frames_clean = false;
+    p->f2_clean[0] = p->f2_clean[1] = false;
 }
 
-void fused_state_zeroed(FusedPlan *p)
+void fused_state_zeroed(FusedPlan *p)  // (all of env.wave in its home buffers)
 {
     p->aux_state = 1;
     p->frames_clean = true;
+    p->f2_clean[0] = true;
 }
 
 static int device_slots(FusedPlan *pl);
@@ -659,12 +898,12 @@ static bool ensure_pair(T **d, T **h, size_t *cap, size_t need, size_t want)
     return true;
 }
 
-int fused_prepare(FusedPlan *p, int slot, float *frames, float *scratch0, float *scratch1, bool capture, const float *G,
-                  const Cyl *d_table, const Cyl *h_table, int M, int rows, hipStream_t s, hipStream_t up, int row_lo, int row_hi)
+int fused_prepare(FusedPlan *p, int slot, float *frames, float *ic, float *out2, int out2_idx, float *scratch0, float *scratch1, bool capture, const float *G,
+                  const Cyl *d_table, const Cyl *h_table, int M, int rows, hipStream_t s, hipStream_t up, int row_lo, int row_hi,
+                  bool defer_wait)
 {
     const Grid &g = p->g;
     const size_t N = g.P * kFields;
-    float *ic = frames + 2 * N;
     p->cur = slot;
     if (p->aux_state < 0) {  // the caller replaced the state: look at it once
         int h = 0;
@@ -687,9 +926,15 @@ int fused_prepare(FusedPlan *p, int slot, float *frames, float *scratch0, float 
                 hipLaunchKernelGGL(k_aux_clean, dim3(1024), dim3(256), 0, s, b, g.nx, g.ny, g.P, g.sx, g.sy);
             p->frames_clean = true;
         }
+        if (!p->f2_clean[out2_idx]) {
+            hipLaunchKernelGGL(k_aux_clean, dim3(1024), dim3(256), 0, s, out2, g.nx, g.ny, g.P, g.sx, g.sy);
+            p->f2_clean[out2_idx] = true;
+        }
+        p->f2_clean[out2_idx ^ 1] = true;  // (the initial condition itself: it satisfies the invariant, as just checked)
     } else {  // this integrate writes non-zero auxiliaries outside the PML
         p->scratch_clean = false;
         if (capture) p->frames_clean = false;
+        p->f2_clean[out2_idx] = false;
     }
     if (!ensure_tiles(p, aux_zero)) return 2;
     static const bool resort = !(getenv("WAVES_AMD_FUSED_RESORT") && atoi(getenv("WAVES_AMD_FUSED_RESORT")) == 0);
@@ -710,7 +955,8 @@ int fused_prepare(FusedPlan *p, int slot, float *frames, float *scratch0, float 
         hipMemcpyAsync(p->d_idx[slot], p->h_idx[slot], p->idx.size() * sizeof(int), hipMemcpyHostToDevice, up) != hipSuccess)
         return 1;
     // everything uploaded so far (the caller's coefficient tables included) before anything of this call runs on s
-    if (up != s && (hipEventRecord(p->up_ev[slot], up) != hipSuccess || hipStreamWaitEvent(s, p->up_ev[slot], 0) != hipSuccess)) return 1;
+    // (a resident launch that is waiting for jobs owns `s`: fused_try_resident then waits for the copy stream on the host)
+    if (up != s && !defer_wait && (hipEventRecord(p->up_ev[slot], up) != hipSuccess || hipStreamWaitEvent(s, p->up_ev[slot], 0) != hipSuccess)) return 1;
     if (G && p->src_dirty) {
         if (nt > p->src_flags_cap) {
             if (p->d_src_flags) (void)hipFree(p->d_src_flags);
@@ -836,25 +1082,160 @@ static int resident_capacity(FusedPlan *pl)
     return device_slots(pl);
 }
 
+// ---- the action-outliving launch: host side ----------------------------------------------------------------------------
+static bool jobs_ensure(FusedPlan *pl, int ntiles)
+{
+    if (!pl->mail) {
+        if (hipHostMalloc((void **)&pl->mail, sizeof(JobMail), hipHostMallocDefault) != hipSuccess) return false;
+        memset((void *)pl->mail, 0, sizeof(JobMail));
+    }
+    if (!pl->back) {
+        if (hipHostMalloc((void **)&pl->back, sizeof(JobBack), hipHostMallocDefault) != hipSuccess) return false;
+        memset((void *)pl->back, 0, sizeof(JobBack));
+    }
+    if (!pl->p_start && (hipEventCreate(&pl->p_start) != hipSuccess || hipEventCreate(&pl->p_stop) != hipSuccess ||
+                         hipEventCreateWithFlags(&pl->p_up, hipEventDisableTiming) != hipSuccess))
+        return false;
+    if (!pl->d_ctl || ntiles > pl->ctl_tiles) {  // (never while a launch is alive: the caller retires it when the tiling changes)
+        if (pl->d_ctl) (void)hipFree(pl->d_ctl);
+        pl->d_ctl = nullptr;
+        const int cap = std::max(ntiles, 1024);
+        if (hipMalloc((void **)&pl->d_ctl, job_ctl_bytes(cap)) != hipSuccess) return false;
+        if (hipMemset(pl->d_ctl, 0, job_ctl_bytes(cap)) != hipSuccess) return false;
+        pl->ctl_tiles = cap;
+    }
+    return true;
+}
+
+// A launch is on the device and has not said that it is leaving.  (One that has said so may still be draining; work
+// enqueued on its stream is ordered behind it either way.)
+bool fused_persist_alive(FusedPlan *pl)
+{
+    if (!pl->p_alive || !pl->p_stays) return false;  // (a launch that ends with its job blocks nothing and takes no further job)
+    return __atomic_load_n(&pl->back->status, __ATOMIC_ACQUIRE) == JOBS_RUNNING;
+}
+
+// the launch has ended (its stop event has fired): bookkeeping
+static void jobs_reap(FusedPlan *pl)
+{
+    if (!pl->p_alive) return;
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, pl->p_start, pl->p_stop) == hipSuccess) {
+        pl->last_launch_ms = ms;
+        pl->last_launch_jobs = (int)(__atomic_load_n(&pl->back->done, __ATOMIC_ACQUIRE) - pl->p_jobs_done_at_launch);
+    } else {
+        (void)hipGetLastError();
+    }
+    pl->p_alive = false;
+}
+
+// Make the launch leave (after the jobs it has been given) and wait until it has.  Everything that wants the context's
+// stream for itself goes through here first: work enqueued behind a launch that idles would wait out its idle limit.
+int fused_retire(FusedPlan *pl)
+{
+    if (!pl || !pl->p_alive) return 0;
+    if (pl->p_stays && __atomic_load_n(&pl->back->status, __ATOMIC_ACQUIRE) == JOBS_RUNNING) {
+        pl->seq++;
+        FusedParams &d = pl->mail->desc[pl->seq & 1u];
+        d = FusedParams{};
+        d.seq = pl->seq;
+        d.cmd = JOB_EXIT;
+        __atomic_store_n(&pl->mail->bell, pl->seq, __ATOMIC_RELEASE);
+    }
+    const hipError_t e = hipEventSynchronize(pl->p_stop);
+    jobs_reap(pl);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return 1;
+    }
+    return 0;
+}
+
+// Would fused_prepare / fused_try_resident enqueue anything on the context's stream for such a call?  (Then a live launch
+// has to be retired first: see fused_retire.)
+bool fused_needs_stream(FusedPlan *pl, bool capture, const float *G, int out2_idx)
+{
+    if (pl->aux_state < 0) return true;
+    const bool aux_zero = pl->aux_state == 1;
+    if (aux_zero && (!pl->scratch_clean || (capture && !pl->frames_clean) || !pl->f2_clean[out2_idx])) return true;
+    if (!pl->tiles_valid || pl->tiles_aux_zero != aux_zero) return true;
+    if (G && pl->src_dirty) return true;
+    if (!pl->d_xch || pl->tag_base > 0xFFFF0000u - (1u << 21)) return true;
+    return false;
+}
+
+static int jobs_launch(FusedPlan *pl, unsigned first_seq, hipStream_t s)
+{
+    // (leftovers of an earlier launch in the go words -- "job n: leave" -- must not be taken for this launch's answer)
+    if (hipMemsetAsync(pl->d_ctl->go, 0, sizeof(pl->d_ctl->go), s) != hipSuccess) return 1;
+    __atomic_store_n(&pl->back->status, (unsigned)JOBS_RUNNING, __ATOMIC_RELEASE);
+    JobArgs a{};
+    a.mail = pl->mail;
+    a.back = pl->back;
+    a.ctl = pl->d_ctl;
+    a.first_seq = first_seq;
+    const unsigned long long ticks = (unsigned long long)pl->idle_us * 100ull;
+    a.idle_ticks = (unsigned)std::min<unsigned long long>(ticks, 0x7fffffffull);
+    a.ntiles = pl->p_ntiles;
+    void *args[1] = {&a};
+    // A plain launch: the grid is at most the number of blocks the device holds at once (resident_capacity, from the
+    // occupancy query -- the same number a cooperative launch would check it against), and an ordinary launch has the same
+    // residency.  hipLaunchCooperativeKernel (WAVES_AMD_COOP=1) additionally serialises the launch against the work of
+    // every other stream of the process.  The launch carries its two events itself (hipExtLaunchKernel: they take the
+    // kernel's own start and end timestamps).
+    static const bool coop = getenv("WAVES_AMD_COOP") && atoi(getenv("WAVES_AMD_COOP")) != 0;
+    hipError_t e;
+    if (coop) {
+        (void)hipEventRecord(pl->p_start, s);
+        e = hipLaunchCooperativeKernel(resident_ptr(pl), dim3((unsigned)pl->p_ntiles), dim3(512), args, 0, s);
+        if (e == hipSuccess) (void)hipEventRecord(pl->p_stop, s);
+    } else {
+        e = hipExtLaunchKernel(resident_ptr(pl), dim3((unsigned)pl->p_ntiles), dim3(512), args, 0, s, pl->p_start, pl->p_stop, 0);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    pl->p_alive = true;
+    pl->n_launches++;
+    pl->p_first = first_seq;
+    pl->p_stream = s;
+    pl->p_jobs_done_at_launch = first_seq - 1;
+    return 0;
+}
+
+// `up`: the stream the caller's uploads of this call went to (its tables must have arrived before the job may start);
+// `ef`: where the trace goes.  keep: the launch may stay on the device after the job (see FusedPlan::persist).
 int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s,
-                       hipEvent_t ev_start, hipEvent_t ev_stop)
+                       hipStream_t up, const FusedEnergy &ef, bool keep)
 {
     pl->cur = slot;
     const size_t nt = pl->hp.tiles.size();
-    if (nsteps < 2 || (int)nt > resident_capacity(pl)) return -1;
+    if (nsteps < 2 || (int)nt > resident_capacity(pl) || (int)nt > JOB_MAX_TILES) return -1;
+    bool alive = fused_persist_alive(pl);
+    if (alive && ((int)nt != pl->p_ntiles || s != pl->p_stream)) {  // (a new tiling: new grid)
+        if (fused_retire(pl)) return 1;
+        alive = false;
+    }
+    if (alive && up == s) {  // (no copy stream: the uploads would queue behind the launch they are meant for)
+        if (fused_retire(pl)) return 1;
+        alive = false;
+    }
+    if (pl->p_alive && !alive) {  // it has said it is leaving (idle, told): wait for the rest of it
+        if (fused_retire(pl)) return 1;
+    }
+    if (!jobs_ensure(pl, (int)nt)) {
+        (void)hipGetLastError();
+        pl->resident_capacity = 0;
+        return -1;
+    }
     // exchange buffer: zeroed once (tag 0 is never expected); tags only grow, so words of earlier calls -- or of an
     // earlier tile decomposition -- can never be mistaken for the ones a step waits for
     const size_t xwords = (size_t)2 * XCH_PLANES * 2 * pl->g.P;  // 8-byte words: 2 parities x 4 planes x P granules of 16 bytes
     if (!pl->d_xch || pl->tag_base > 0xFFFF0000u - (unsigned)nsteps) {
-        // (Experiment knob WAVES_AMD_XCH_ALLOC=3 / 1: uncached / fine-grained device memory for the exchange buffer.  Uncached
-        // shortens a step by 0.8 % at 700^2 (profiles/r02/ab_xalloc.txt) but is NOT the default: with it a later context of
-        // the same process returned wrong trajectory planes in tests/test_gpu_parity.py -- memory handed back by hipFree
-        // after an uncached allocation did not behave like ordinary device memory on ROCm 7.2.)
-        static const int xalloc = getenv("WAVES_AMD_XCH_ALLOC") ? atoi(getenv("WAVES_AMD_XCH_ALLOC")) : 0;
-        if (!pl->d_xch && xalloc &&
-            hipExtMallocWithFlags((void **)&pl->d_xch, xwords * sizeof(unsigned long long), (unsigned)xalloc) != hipSuccess) {
-            (void)hipGetLastError();
-            pl->d_xch = nullptr;
+        if (alive) {  // (fused_needs_stream says so beforehand; a call that got here all the same takes the long way)
+            if (fused_retire(pl)) return 1;
+            alive = false;
         }
         if (!pl->d_xch && hipMalloc((void **)&pl->d_xch, xwords * sizeof(unsigned long long)) != hipSuccess) {
             (void)hipGetLastError();
@@ -883,10 +1264,10 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
             if (hipMalloc((void **)&pl->d_steps[slot], tab.size() * sizeof(StepIO)) != hipSuccess) return 1;
             pl->steps_cap[slot] = tab.size();
         }
-        // (rare: the table only changes with the call's shape.  The slot's previous launch has been ended by the caller;
-        // the host vector is not touched again before the slot's next call)
+        // (rare: the table only changes with the call's shape.  The slot's previous call has been ended by the caller;
+        // the host vector is not touched again before the slot's next call.  On the copy stream: a live launch owns `s`.)
         pl->h_steps[slot] = tab;
-        if (hipMemcpyAsync(pl->d_steps[slot], pl->h_steps[slot].data(), tab.size() * sizeof(StepIO), hipMemcpyHostToDevice, s) != hipSuccess)
+        if (hipMemcpyAsync(pl->d_steps[slot], pl->h_steps[slot].data(), tab.size() * sizeof(StepIO), hipMemcpyHostToDevice, up) != hipSuccess)
             return 1;
     }
     FusedParams p = make_params(pl, call, 0, steps[0]);
@@ -899,66 +1280,184 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
     const char *mp = getenv("WAVES_AMD_WAIT_POLLS");  // diagnostic, read per call (tests force a give-up with it)
     p.max_polls = (mp && atoi(mp) > 0) ? atoi(mp) : pl->max_polls;
     p.abort = pl->d_abort;
-    void *args[1] = {&p};
-    // A plain launch: the grid is at most the number of blocks the device holds at once (resident_capacity, from the
-    // occupancy query -- the same number a cooperative launch would check it against), and an ordinary launch has the same
-    // residency.  hipLaunchCooperativeKernel (WAVES_AMD_COOP=1) additionally serialises the launch against the work of
-    // every other stream of the process: the copy stream's transfers (streamed trajectories, table uploads) then no
-    // longer overlap the kernel, and each launch costs the host ~17 us more.
-    static const bool coop = getenv("WAVES_AMD_COOP") && atoi(getenv("WAVES_AMD_COOP")) != 0;
-    // With a pair of events the launch carries them itself (hipExtLaunchKernel: the events take the kernel's own start and
-    // end timestamps): two hipEventRecord calls -- two barrier packets between consecutive actions -- less per action, and
-    // the measured duration is the kernel's, without the gap between an event packet and the dispatch behind it.
-    // (WAVES_AMD_EXT_EVENTS=0: separate event records around a plain launch, as before -- A/B)
-    static const bool ext = !(getenv("WAVES_AMD_EXT_EVENTS") && atoi(getenv("WAVES_AMD_EXT_EVENTS")) == 0);
-    hipError_t e;
-    if (coop || !ext) {
-        if (ev_start) (void)hipEventRecord(ev_start, s);
-        e = coop ? hipLaunchCooperativeKernel(resident_ptr(pl), dim3((unsigned)nt), dim3(512), args, 0, s)
-                 : hipLaunchKernel(resident_ptr(pl), dim3((unsigned)nt), dim3(512), args, 0, s);
-        if (ev_stop && e == hipSuccess) (void)hipEventRecord(ev_stop, s);
-    } else if (ev_start && ev_stop) {
-        e = hipExtLaunchKernel(resident_ptr(pl), dim3((unsigned)nt), dim3(512), args, 0, s, ev_start, ev_stop, 0);
-    } else {
-        e = hipLaunchKernel(resident_ptr(pl), dim3((unsigned)nt), dim3(512), args, 0, s);
+    p.seq = pl->seq + 1;
+    p.cmd = JOB_RUN;
+    p.last = (keep && pl->persist && pl->allow_persist && !pl->stamps_path) ? 0 : 1;
+    p.ntiles = (int)nt;
+    p.ef_row0 = ef.row0;
+    p.ef_epart = ef.epart;
+    p.ef_signal = ef.signal;
+    p.ef_dOmega = ef.dOmega;
+    p.ctl = pl->d_ctl;
+    static const bool joblog_ = getenv("WAVES_AMD_JOBLOG") != nullptr;
+    p.back = joblog_ ? pl->back : nullptr;
+    // Everything the job reads must be in device memory before the bell rings.  A launch that is already there cannot be
+    // made to wait by the stream, so the host waits for the copy stream itself (the uploads are ~100 KB: they are long
+    // done when the previous job ends, and in the two-in-flight rhythm this wait sits under that job).
+    if (alive) {
+        if (hipEventRecord(pl->p_up, up) != hipSuccess) return 1;
+        hipError_t q;
+        while ((q = hipEventQuery(pl->p_up)) == hipErrorNotReady) {}
+        if (q != hipSuccess) {
+            (void)hipGetLastError();
+            return 1;
+        }
+        if (!fused_persist_alive(pl)) {  // it left meanwhile (idle limit)
+            if (fused_retire(pl)) return 1;
+            alive = false;
+        }
     }
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        pl->resident_capacity = 0;  // do not try again
-        return -1;
+    if (!alive && up != s) {  // the new launch waits in stream order
+        if (hipEventRecord(pl->p_up, up) != hipSuccess || hipStreamWaitEvent(s, pl->p_up, 0) != hipSuccess) return 1;
+    }
+    pl->seq++;
+    pl->mail->desc[pl->seq & 1u] = p;
+    __atomic_store_n(&pl->mail->bell, pl->seq, __ATOMIC_RELEASE);
+    if (!alive) {
+        pl->p_ntiles = (int)nt;
+        const int rc = jobs_launch(pl, pl->seq, s);
+        if (rc != 0) {
+            pl->seq--;  // (nobody has seen the description)
+            __atomic_store_n(&pl->mail->bell, pl->seq, __ATOMIC_RELEASE);
+            if (rc < 0) pl->resident_capacity = 0;  // do not try again
+            return rc;
+        }
     }
     pl->tag_base += (unsigned)nsteps;
-    pl->abort_pending[slot] = true;  // (the caller has the give-up word copied to fused_abort_dst(slot) behind the launch)
+    pl->n_jobs++;
+    pl->n_handed += alive ? 1 : 0;
+    pl->job_seq[slot] = pl->seq;
+    pl->job_keep[slot] = p.last == 0;
+    pl->job_rows[slot] = ef.signal ? std::min(nsteps + 1, (int)nt) : 0;
+    pl->p_stays = p.last == 0;
+    pl->abort_pending[slot] = true;
     return 0;
+}
+
+// Wait for the slot's resident call.  0: done; 2: the launch gave the call up -- its initial condition is intact (the final state has a buffer of its own)
+// and the caller runs it again with the single-step kernels (fused_rerun_steps); 1: HIP error.  A launch that left on its
+// idle limit before it saw the job is started again here.
+int fused_job_wait(FusedPlan *pl, int slot, hipStream_t s)
+{
+    const unsigned want = pl->job_seq[slot];
+    if (!want) return 0;
+    pl->job_seq[slot] = 0;
+    pl->abort_pending[slot] = false;
+    unsigned spins = 0;
+    const int writers = pl->job_rows[slot];  // blocks that put trace rows into host memory (0: no trace wanted)
+    pl->job_rows[slot] = 0;
+    auto complete = [&]() {
+        if (!job_reached(__atomic_load_n(&pl->back->done, __ATOMIC_ACQUIRE), want)) return false;
+        for (int k = writers - 1; k >= 0; --k)
+            if (!job_reached(__atomic_load_n(&pl->back->rowdone[k], __ATOMIC_ACQUIRE), want)) return false;
+        return true;
+    };
+    for (;;) {
+        if (complete()) break;
+        if ((++spins & 1023u) != 0) continue;
+        // not done yet: is the launch still there?
+        if (pl->p_alive && hipEventQuery(pl->p_stop) == hipSuccess) {
+            if (complete()) break;
+            const unsigned why = __atomic_load_n(&pl->back->status, __ATOMIC_ACQUIRE);
+            jobs_reap(pl);
+            if (why == JOBS_EXIT_ABORT) return 2;
+            // left on its idle limit (or told to) without having seen this job: the description and the bell are still
+            // there -- a new launch takes over from this job on
+            const unsigned done = __atomic_load_n(&pl->back->done, __ATOMIC_ACQUIRE);
+            const int rc = jobs_launch(pl, done + 1, s);
+            if (rc != 0) return 1;
+        } else if (!pl->p_alive) {
+            const unsigned why = __atomic_load_n(&pl->back->status, __ATOMIC_ACQUIRE);
+            if (why == JOBS_EXIT_ABORT) return 2;
+            const unsigned done = __atomic_load_n(&pl->back->done, __ATOMIC_ACQUIRE);
+            if (complete()) break;
+            const int rc = jobs_launch(pl, done + 1, s);
+            if (rc != 0) return 1;
+        } else {
+            (void)hipGetLastError();  // (hipErrorNotReady)
+        }
+    }
+    // in-kernel duration of the job (the leader's 100 MHz stamps)
+    const unsigned par = want & 1u;
+    const unsigned long long t0 = pl->back->t_begin[par], t1 = pl->back->t_end[par];
+    const double ms = t1 > t0 ? (double)(t1 - t0) * 1e-5 : 0.0;
+    static const bool joblog = getenv("WAVES_AMD_JOBLOG") != nullptr;  // diagnostic: the device clock of every job
+    if (joblog) {
+        static unsigned long long prev_end = 0;
+        fprintf(stderr, "[waves_amd job] seq %u begin %llu end %llu: %.2f us, %.2f us after the previous job's end\n", want, t0, t1,
+                (double)(t1 - t0) * 0.01, prev_end ? (double)((long long)(t0 - prev_end)) * 0.01 : 0.0);
+        prev_end = t1;
+        const unsigned long long *ph = pl->back->phase[par];
+        fprintf(stderr, "    phases (us after begin): go seen by all %.2f | state loaded %.2f | steps done %.2f | (unused) %.2f | stores drained %.2f | "
+                        "barrier B %.2f | end %.2f\n", (double)(long long)(ph[0] - t0) * 0.01, (double)(long long)(ph[1] - t0) * 0.01,
+                (double)(long long)(ph[2] - t0) * 0.01, (double)(long long)(ph[3] - t0) * 0.01, (double)(long long)(ph[4] - t0) * 0.01,
+                (double)(long long)(ph[5] - t0) * 0.01, (double)(long long)(t1 - t0) * 0.01);
+    }
+    pl->last_job_ms = ms;
+    if (pl->job_ms.size() < (size_t)1 << 16) pl->job_ms.push_back(ms);
+    if (!pl->job_keep[slot]) {  // the launch ended with this job: take its stop event so that its duration is known
+        if (pl->p_alive) {       // (polled: the kernel is a few microseconds from its end, a blocking wait costs far more)
+            hipError_t e;
+            unsigned n = 0;
+            while ((e = hipEventQuery(pl->p_stop)) == hipErrorNotReady && ++n < (1u << 22)) {}
+            if (e == hipErrorNotReady) e = hipEventSynchronize(pl->p_stop);
+            jobs_reap(pl);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                return 1;
+            }
+        }
+    }
+    return 0;
+}
+
+// after a give-up: the protocol is reset so that the context stays usable, and this context stays on the single-step
+// kernels from now on: whatever kept a tile from running (another process's kernels on the same device, most likely) may
+// well still be there at the next call
+void fused_gave_up(FusedPlan *pl, hipStream_t s)
+{
+    if (pl->p_alive) {
+        (void)hipEventSynchronize(pl->p_stop);
+        jobs_reap(pl);
+    }
+    (void)hipMemsetAsync(pl->d_abort, 0, sizeof(int), s);
+    pl->use_resident = false;
+    for (int k = 0; k < 2; ++k) {
+        pl->job_seq[k] = 0;
+        pl->abort_pending[k] = false;
+    }
 }
 
 const int *fused_abort_src(const FusedPlan *p) { return p->d_abort; }
 int *fused_abort_dst(FusedPlan *p, int slot) { return p->h_abort + slot; }
 
-int fused_finish(FusedPlan *pl, int slot, hipStream_t s)
+double fused_last_job_ms(const FusedPlan *p) { return p->last_job_ms; }
+void fused_launch_stats(const FusedPlan *p, double *ms, int *jobs)
 {
-    if (!pl->abort_pending[slot]) return 0;
-    pl->abort_pending[slot] = false;
-    if (pl->h_abort[slot] == 0) return 0;
-    // a tile gave up waiting: the state is garbage.  Reset the protocol so that the context stays usable, and keep this
-    // context on the single-step kernels from now on: whatever kept a tile from running (another process's kernels on
-    // the same device, most likely) may well still be there at the next call.  (A call already enqueued behind this one
-    // sees the word too and drains at once; its own verdict says so.)
-    pl->h_abort[slot] = 0;
-    (void)hipMemsetAsync(pl->d_abort, 0, sizeof(int), s);
-    pl->use_resident = false;
-    return 1;
+    *ms = p->last_launch_ms;
+    *jobs = p->last_launch_jobs;
 }
+void fused_allow_persist(FusedPlan *p, bool allow) { p->allow_persist = allow; }
 
 static int fused_run_steps(FusedPlan *pl, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s, hipEvent_t ev_start);
 
-int fused_run(FusedPlan *pl, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s, hipEvent_t ev_start,
-              hipEvent_t ev_stop)
+int fused_run(FusedPlan *pl, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s, hipStream_t up,
+              const FusedEnergy &ef, bool keep, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
-    const int rr = fused_try_resident(pl, slot, call, steps, nsteps, s, ev_start, ev_stop);
+    const int rr = fused_try_resident(pl, slot, call, steps, nsteps, s, up, ef, keep);
     pl->cur = slot;
     pl->last_resident = rr == 0;
     if (rr >= 0) return rr;
+    const int rc = fused_run_steps(pl, slot, call, steps, nsteps, s, ev_start);
+    if (ev_stop && hipEventRecord(ev_stop, s) != hipSuccess) return 1;
+    return rc;
+}
+
+// the same call once more with the single-step kernels (after fused_job_wait returned 2)
+int fused_rerun_steps(FusedPlan *pl, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s,
+                      hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    pl->cur = slot;
     const int rc = fused_run_steps(pl, slot, call, steps, nsteps, s, ev_start);
     if (ev_stop && hipEventRecord(ev_stop, s) != hipSuccess) return 1;
     return rc;

@@ -19,6 +19,11 @@ def env_rank() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def shares_device(world: int, local_rank: int, ndev: int) -> bool:
+    """True when the ranks of this node cannot each have a GPU of their own (ndev = visible devices, 0 = CPU-only run)."""
+    return ndev > 0 and (world > ndev or local_rank >= ndev)
+
+
 def init(backend: str | None = None):
     """Initialise torch.distributed if WORLD_SIZE > 1.  backend None -> "nccl" (= RCCL) when a GPU is visible, else gloo."""
     import torch
@@ -26,10 +31,17 @@ def init(backend: str | None = None):
     rank, local_rank, world = env_rank()
     if world == 1 and not os.environ.get("WAVES_AMD_FORCE_DIST"):  # (the variable lets a 1-GPU box exercise the RCCL path)
         return rank, local_rank, world
+    ndev = torch.cuda.device_count()
+    if shares_device(world, local_rank, ndev):
+        # Ranks that share a GPU (rehearsals on a one-GPU box, WAVES_AMD_ALLOW_SHARED_GPU=1) must not use the resident step
+        # kernel: it needs ALL its tiles on the device at once, the library counts contexts per PROCESS, and two processes'
+        # resident grids can each end up partly resident -- every tile then polls in vain until the launch gives up.
+        # Decided here, before any Context exists, for every caller (bench.py, tools/rollout.py, user scripts).
+        os.environ["WAVES_AMD_FUSED_RESIDENT"] = "0"
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
         # a rehearsal with several ranks on ONE GPU (WAVES_AMD_ALLOW_SHARED_GPU=1): RCCL refuses two ranks on a device
-        if backend == "nccl" and os.environ.get("WAVES_AMD_ALLOW_SHARED_GPU") and torch.cuda.device_count() < world:
+        if backend == "nccl" and os.environ.get("WAVES_AMD_ALLOW_SHARED_GPU") and ndev < world:
             backend = "gloo"
     if backend == "nccl":
         n = torch.cuda.device_count()
