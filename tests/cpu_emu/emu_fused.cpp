@@ -9,10 +9,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #define WV_XCH_DEBUG 1
-static int wv_xch_debug = 0;
+static thread_local int wv_xch_debug = 0;
 #include "../../waves.jl_amd/csrc/fused_plan.h"
 
 extern "C" {
@@ -27,11 +29,12 @@ int wo_integrate(int nx, int ny, const float *x, const float *y, const float *sx
 
 using namespace wv;
 
-static F2 g_lds_raw[lds_elems(8 * 6)];  // deliberately NOT cleared between tiles: stale contents must never matter
+// (thread_local: the job-protocol emulation runs every block of a launch as a thread of its own)
+static thread_local F2 g_lds_raw[lds_elems(8 * 6)];  // deliberately NOT cleared between tiles: stale contents must never matter
 
-static bool g_probe_only = false;  // resident emulation: only poll the halo, do not run the step
+static thread_local bool g_probe_only = false;  // resident emulation: only poll the halo, do not run the step
 static int g_maxdrift = 0;
-static bool g_not_ready = false;  // set by a resident tile whose halo words have not all arrived
+static thread_local bool g_not_ready = false;  // set by a resident tile whose halo words have not all arrived
 static int g_force_all = 0;  // 1: every tile runs the F_ALL instantiation (must give the same bits as the specialised ones)
 
 // Registers of one tile (type-erased: the register struct depends on the variant), kept from step to step in the
@@ -422,6 +425,313 @@ static int run_case(const Case &cs)
     return (bad || emax > 1e-6) ? 1 : 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The JOB protocol of k_steps_resident (fused_body.h "jobs", kernels_fused.hip): one launch serves several wv_integrate
+// calls.  Every block of the launch is a thread here and runs the kernel's job loop with the SAME protocol functions the
+// device runs (job_leader_fetch / job_try_fetch / job_wait_go / job_barrier: compiled for the host they use C++ atomics),
+// around the emulated tile steps; another thread plays the host API: it describes jobs in the mailbox, rings the bell
+// late, early (so that the leader's look-ahead under barrier B finds the next job) or not at all (idle limit), tells the
+// launch to leave, or forces a give-up.  Checked: every job's final state bit for bit against the oracle although the
+// tile -> block mapping changes from job to job (the state travels through memory between jobs), the traces, that the
+// initial condition of an abandoned job is intact, and that the launch DRAINS -- every block thread ends -- on every path.
+static std::atomic<unsigned long long> g_vclock{0};
+unsigned long long wv::emu_job_clock() { return g_vclock.fetch_add(1, std::memory_order_relaxed); }
+void wv::emu_job_pause() { std::this_thread::yield(); }
+
+struct EmuLaunch {
+    JobArgs args;
+    int key;
+    std::vector<float> *epart;     // [job & 1][step][tile][3]: the tiles' partial sums (what the device keeps in d_epart)
+    std::vector<double> *rows;     // [job & 1][(nsteps + 1)][3]: the trace the blocks reduce ("pinned host memory")
+    std::atomic<int> running{0};
+};
+
+static void emu_block(EmuLaunch *E, int b)
+{
+    const JobArgs &a = E->args;
+    unsigned seq = a.first_seq, pref_seq = 0;
+    int pref_cmd = 0;
+    for (;;) {
+        int cmd;
+        if (b == 0) {
+            cmd = pref_seq == seq ? pref_cmd : job_leader_fetch(a, seq, 0);
+            if (cmd == JOB_RUN) job_st_sys64(&a.back->t_begin[seq & 1u], job_clock());
+        } else {
+            cmd = job_wait_go(a, seq);
+        }
+        if (cmd != JOB_RUN) break;
+        const FusedParams &p = a.ctl->jobs[seq & 1u];
+        const TileDesc t = p.tiles[b];
+        TileMem mem;
+        bool ok = true;
+        for (int s = 0; s < p.nsteps && ok; ++s) {
+            double es[3] = {0, 0, 0};
+            for (int polls = 0;; ++polls) {
+                g_not_ready = false;
+                run_dispatch(E->key, p, p.steps[s], t, es, mem, s == 0 ? MODE_RESIDENT_FIRST : MODE_RESIDENT_NEXT);
+                if (!g_not_ready) break;
+                if (polls >= p.max_polls || job_ld_agent(reinterpret_cast<const unsigned *>(p.abort)) != 0u) {
+                    job_st_agent(reinterpret_cast<unsigned *>(p.abort), 1u);
+                    ok = false;
+                    break;
+                }
+                job_pause();
+            }
+            if (ok)
+                for (int c = 0; c < 3; ++c) job_st_agentf(&(*E->epart)[(((size_t)(seq & 1u) * (p.nsteps + 1) + s + 1) * p.ntiles + t.slot) * 3 + c], (float)es[c]);
+        }
+        if (!ok) {
+            job_st_sys(&a.back->exit_seq[a.launch], seq);
+            job_st_sys(&a.back->status[a.launch], JOBS_EXIT_ABORT);
+            break;
+        }
+        if (b == 0 && !p.last) {  // the leader's second wave looks for the next job under barrier B
+            const int c2 = job_try_fetch(a, seq + 1u, 0);
+            pref_seq = c2 != 0 ? seq + 1u : 0u;
+            pref_cmd = c2;
+        }
+        if (!job_barrier(job_flags(a.ctl, 1, p.ntiles), p.ntiles, b, seq, p.max_polls, p.abort, 0)) {
+            job_st_agent(reinterpret_cast<unsigned *>(p.abort), 2u);
+            job_st_sys(&a.back->status[a.launch], JOBS_EXIT_ABORT);
+            break;
+        }
+        const int nrows = p.nsteps + 1;
+        for (int row = b; row < nrows; row += p.ntiles) {
+            if (row == 0) continue;  // (the initial state's energies: not part of this emulation)
+            for (int c = 0; c < 3; ++c) {
+                double sum = 0.0;
+                for (int k = 0; k < p.ntiles; ++k) sum += (double)job_ld_agentf(&(*E->epart)[(((size_t)(seq & 1u) * nrows + row) * p.ntiles + k) * 3 + c]);
+                (*E->rows)[((size_t)(seq & 1u) * nrows + row) * 3 + c] = sum;
+            }
+        }
+        if (b < nrows) job_st_sys(&a.back->rowdone[b], seq);
+        if (b == 0) {
+            job_st_sys64(&a.back->t_end[seq & 1u], job_clock());
+            if (p.last) job_st_sys(&a.back->status[a.launch], JOBS_EXIT_LAST);
+            job_st_sys(&a.back->done, seq);
+        }
+        if (p.last) break;
+        ++seq;
+    }
+    E->running.fetch_sub(1);
+}
+
+static int run_jobs(const char *name, int scenario)
+{
+    const int n = 131, nsteps = 5, njobs = 4, NW = 8, RF = 2, RB = 2, RP = 2, M = 5;
+    const size_t P = (size_t)n * n, N = 12 * P;
+    std::vector<float> x(n), sx(n);
+    for (int i = 0; i < n; ++i) x[i] = (float)(-15.0 + 30.0 * i / (n - 1));
+    wo_build_pml_profile(n, x.data(), 2.0f, 20000.0f, sx.data());
+    const float c0 = 1531.0f, dt = 1e-5f, freq = 1000.0f, hdt = 0.5f * dt;
+    std::vector<float> G(P, 0.0f);
+    for (size_t q = 0; q < P; ++q) {
+        const float xx = x[q % n] - 1.0f, yy = x[q / n] + 0.5f;
+        G[q] = (float)exp(-(xx * xx + yy * yy) / 0.18);
+    }
+    // state buffers: frames are not captured here; the last frame alternates between two buffers (wv_ctx::cur2)
+    std::vector<float> buf[2], scratch[2];
+    buf[0].assign(N, 0.0f);
+    buf[1].assign(N, 0.0f);
+    scratch[0].assign(N, 0.0f);
+    scratch[1].assign(N, 0.0f);
+    for (int f = 0; f < 12; ++f)
+        for (size_t q = 0; q < P; ++q) {
+            const int i = (int)(q % n), j = (int)(q / n), k = f % 6;
+            float v = (float)(0.1 * (urand() - 0.5));
+            const bool zx = sx[i] == 0.0f, zy = sx[j] == 0.0f;
+            if ((k == 3 && zx) || (k == 4 && zy) || (k == 5 && (zx || zy))) v = 0.0f;
+            buf[0][(size_t)f * P + q] = v;
+        }
+    std::vector<float> ref = buf[0];
+    HostPlan pl;
+    g_force_all = 0;
+    if (!plan_build_tiles(pl, n, n, NW * RF, NW * RB, NW * RP, x.data(), x.data(), sx.data(), sx.data(), true, true)) return 1;
+    const int nt = (int)pl.tiles.size();
+    std::vector<unsigned char> flags(nt, 0);
+    for (const TileDesc &t : pl.tiles)
+        for (int gy = t.y0 - FT_H; gy < t.y0 + t.oy + FT_H; ++gy)
+            for (int gx = t.x0 - FT_H; gx < t.x0 + t.ox + FT_H; ++gx)
+                if (gx >= 0 && gx < n && gy >= 0 && gy < n && G[(size_t)gy * n + gx] != 0.0f) flags[t.slot] = 1;
+    // the launch's shared memory
+    JobMail mail{};
+    JobBack back{};
+    std::vector<unsigned long long> ctlmem((job_ctl_bytes(nt) + 7) / 8, 0ull);
+    JobCtl *ctl = reinterpret_cast<JobCtl *>(ctlmem.data());
+    std::vector<unsigned long long> xch((size_t)2 * XCH_PLANES * 2 * P, 0ull);
+    int abort_word[4] = {0, 0, 0, 0};
+    std::vector<float> epart((size_t)2 * (nsteps + 1) * nt * 3, 0.0f);
+    std::vector<double> rows((size_t)2 * (nsteps + 1) * 3, 0.0);
+    // per-job tables (two slots, like the library)
+    std::vector<Cyl> table[2];
+    std::vector<float> sfac[2];
+    std::vector<TileDesc> tiles[2];
+    std::vector<int> idx[2];
+    std::vector<StepIO> steps[2];
+    std::vector<std::thread> th;
+    EmuLaunch E;
+    E.key = NW * 1000 + RF * 100 + RB * 10 + RP;
+    E.epart = &epart;
+    E.rows = &rows;
+    auto launch = [&](unsigned first, int l) {
+        memset((void *)ctl->go, 0, sizeof(ctl->go));
+        back.status[l] = JOBS_RUNNING;
+        E.args = JobArgs{&mail, &back, ctl, first, scenario == 2 ? 200000u : 100000000u, nt, l};
+        E.running = nt;
+        for (int b = 0; b < nt; ++b) th.emplace_back(emu_block, &E, b);
+    };
+    auto join = [&]() {
+        for (std::thread &t : th) t.join();
+        th.clear();
+    };
+    unsigned tag_base = 4094, seq = 0;
+    int cur = 0, fails = 0, launch_idx = 0, idle_exits = 0;
+    bool alive = false;
+    float t_now = 0.002f;
+    std::vector<float> want_ic;
+    for (int j = 0; j < njobs; ++j) {
+        const int slot = j & 1;
+        // a fresh design per job (the culling and the launch order change with it), the oracle's result
+        std::vector<float> d0(4 * (size_t)M), d1(4 * (size_t)M), tspan(nsteps + 1);
+        for (int m = 0; m < M; ++m) {
+            d0[4 * m + 0] = (float)(20.0 * (urand() - 0.5));
+            d0[4 * m + 1] = (float)(20.0 * (urand() - 0.5));
+            d0[4 * m + 2] = (float)(0.5 + 2.0 * urand());
+            d0[4 * m + 3] = (float)(600.0 + 2000.0 * urand());
+            for (int k = 0; k < 4; ++k) d1[4 * m + k] = d0[4 * m + k] + (k < 3 ? (float)(0.5 * (urand() - 0.5)) : 0.0f);
+        }
+        for (int s = 0; s <= nsteps; ++s) tspan[s] = (float)((double)t_now + (double)s * 1e-5);
+        t_now = tspan[nsteps];
+        std::vector<double> eref(3 * (size_t)(nsteps + 1));
+        want_ic = ref;
+        wo_integrate(n, n, x.data(), x.data(), sx.data(), sx.data(), c0, dt, ref.data(), tspan.data(), nsteps, G.data(), freq, M, d0.data(),
+                     d1.data(), tspan[0], tspan[nsteps], eref.data(), nullptr, nullptr, 0, 4);
+        table[slot].assign(3 * (size_t)nsteps * M, Cyl{});
+        sfac[slot].assign(3 * (size_t)nsteps, 0.0f);
+        std::vector<float> tmp(4 * (size_t)M);
+        for (int s = 0; s < nsteps; ++s) {
+            const float tq[3] = {tspan[s], tspan[s] + hdt, tspan[s] + dt};
+            for (int q = 0; q < 3; ++q) {
+                sfac[slot][3 * s + q] = wo_source_factor(tq[q], freq);
+                wo_design_at(M, d0.data(), d1.data(), tspan[0], tspan[nsteps], tq[q], tmp.data());
+                for (int m = 0; m < M; ++m) table[slot][(size_t)(3 * s + q) * M + m] = Cyl{tmp[4 * m], tmp[4 * m + 1], tmp[4 * m + 2] * tmp[4 * m + 2], tmp[4 * m + 3]};
+            }
+        }
+        plan_build_cyl(pl, x.data(), x.data(), table[slot].data(), M, 3 * nsteps, idx[slot], true, nt / 2 + 1);  // (pair order: a per-job permutation)
+        tiles[slot] = pl.tiles;
+        for (size_t k = 0; k + 1 < tiles[slot].size(); ++k)  // ... and a random one on top: block b's tile differs from job to job
+            std::swap(tiles[slot][k], tiles[slot][k + (size_t)(urand() * (double)(tiles[slot].size() - k))]);
+        steps[slot].resize(nsteps);
+        float *in = buf[cur].data();
+        for (int s = 0; s < nsteps; ++s) {
+            float *out = s + 1 == nsteps ? buf[cur ^ 1].data() : scratch[s & 1].data();
+            steps[slot][s] = StepIO{in, s + 1 == nsteps ? out : nullptr, nullptr, nullptr, nullptr, s, 0};
+            in = out;
+        }
+        FusedParams p{};
+        p.nx = n; p.ny = n; p.P = (unsigned)P;
+        const float delta = (x[n - 1] - x[0]) / (float)(n - 1), two_d = 2.0f * delta;
+        p.ops = Ops{-1.0f / two_d, 1.0f / two_d, -3.0f / two_d, 4.0f / two_d, -1.0f / two_d, 1.0f / two_d, -4.0f / two_d, 3.0f / two_d};
+        p.x = x.data(); p.y = x.data(); p.sx = sx.data(); p.sy = sx.data();
+        p.c0 = c0; p.c0sq = c0 * c0;
+        p.G = G.data(); p.src_flags = flags.data();
+        p.sfac_tab = sfac[slot].data(); p.cyl_tab = table[slot].data(); p.M = M;
+        p.dt = dt; p.hdt = hdt;
+        p.tiles = tiles[slot].data(); p.cyl_idx = idx[slot].data();
+        p.steps = steps[slot].data(); p.nsteps = nsteps;
+        p.xch = xch.data(); p.xch_bytes = (unsigned)(xch.size() * 8);
+        p.tag_base = tag_base; p.reduced = 1;
+        p.max_polls = (scenario == 3 && j == 2) ? 1 : (1 << 26);
+        p.abort = abort_word;
+        p.seq = seq + 1; p.cmd = JOB_RUN; p.last = (scenario == 1 && j == 1) ? 1 : 0;
+        p.ntiles = nt; p.ctl = ctl;
+        // the API side: describe, ring (scenario 2: the launch has been left waiting past its idle limit before job 2)
+        if (scenario == 2 && j == 2 && alive) {
+            while (__atomic_load_n(&back.status[launch_idx], __ATOMIC_ACQUIRE) == JOBS_RUNNING) std::this_thread::yield();
+            join();
+            alive = false;
+            if (back.status[launch_idx] != JOBS_EXIT_IDLE) { printf("%-28s expected an idle exit\n", name); return 1; }
+            ++idle_exits;
+        }
+        if (alive && __atomic_load_n(&back.status[launch_idx], __ATOMIC_ACQUIRE) != JOBS_RUNNING) {  // (it left meanwhile: fused_try_resident)
+            join();
+            alive = false;
+            ++idle_exits;
+        }
+        ++seq;
+        mail.desc[seq & 1u] = p;
+        __atomic_store_n(&mail.bell, seq, __ATOMIC_RELEASE);
+        if (!alive) {
+            launch_idx ^= 1;
+            launch(seq, launch_idx);
+            alive = true;
+        }
+        tag_base += (unsigned)nsteps;
+        // wait for the job as fused_job_wait does
+        bool gave_up = false;
+        for (;;) {
+            bool done = job_reached(__atomic_load_n(&back.done, __ATOMIC_ACQUIRE), seq);
+            for (int k = 0; done && k < std::min(nsteps + 1, nt); ++k) done = job_reached(__atomic_load_n(&back.rowdone[k], __ATOMIC_ACQUIRE), seq);
+            if (done) break;
+            if (E.running.load() == 0) {
+                bool d2 = job_reached(__atomic_load_n(&back.done, __ATOMIC_ACQUIRE), seq);
+                if (d2) continue;
+                gave_up = back.status[launch_idx] == JOBS_EXIT_ABORT;
+                if (gave_up) break;
+                // it left on its idle limit before it saw this job (the emulated host can be slow): the description and the
+                // bell are still there -- a new launch takes over from the first job that is not done (fused_job_wait)
+                join();
+                ++idle_exits;
+                launch_idx ^= 1;
+                launch(__atomic_load_n(&back.done, __ATOMIC_ACQUIRE) + 1, launch_idx);
+            }
+            std::this_thread::yield();
+        }
+        if (gave_up || !job_reached(back.done, seq)) {
+            join();
+            alive = false;
+            if (scenario != 3 || j != 2) { printf("%-28s job %d was not completed (status %u)\n", name, j, back.status[launch_idx]); return 1; }
+            // the give-up: every block has ended (join returned), and the job's initial condition is intact
+            size_t bad = 0;
+            for (size_t q = 0; q < N; ++q) bad += buf[cur][q] == want_ic[q] ? 0 : 1;
+            printf("%-28s job %d given up as forced, launch drained, initial condition %s\n", name, j, bad ? "DAMAGED" : "intact");
+            return bad ? 1 : 0;
+        }
+        cur ^= 1;
+        size_t bad = 0;
+        for (size_t q = 0; q < N; ++q) bad += buf[cur][q] == ref[q] ? 0 : 1;
+        double emax = 0.0;
+        for (int s = 1; s <= nsteps; ++s)
+            for (int c = 0; c < 3; ++c) {
+                const double r = eref[3 * (size_t)s + c];
+                emax = fmax(emax, fabs(rows[((size_t)(seq & 1u) * (nsteps + 1) + s) * 3 + c] - r) / (fabs(eref[3 * (size_t)s]) + 1e-300));
+            }
+        if (bad || emax > 1e-6) {
+            printf("%-28s job %d: %zu cells differ, energy rel %.1e\n", name, j, bad, emax);
+            ++fails;
+        }
+        if (p.last) {  // the launch ended with this job
+            join();
+            alive = false;
+            if (back.status[launch_idx] != JOBS_EXIT_LAST) { printf("%-28s expected the launch to end with job %d\n", name, j); return 1; }
+        }
+    }
+    if (alive) {  // tell it to leave (fused_retire) and see that it does
+        ++seq;
+        FusedParams d{};
+        d.seq = seq;
+        d.cmd = JOB_EXIT;
+        mail.desc[seq & 1u] = d;
+        __atomic_store_n(&mail.bell, seq, __ATOMIC_RELEASE);
+        join();
+        if (back.status[launch_idx] != JOBS_EXIT_TOLD) { printf("%-28s expected the launch to leave when told (status %u)\n", name, back.status[launch_idx]); return 1; }
+    }
+    if (scenario == 2 && idle_exits == 0) { printf("%-28s no idle exit happened\n", name); return 1; }
+    printf("%-28s %d jobs x %d steps on %d block threads, tile -> block mapping changed per job, %d idle exit(s): %s\n", name, njobs, nsteps,
+           nt, idle_exits, fails ? "MISMATCH" : "bit-exact (jobs)");
+    return fails;
+}
+
 int main(int argc, char **argv)
 {
     const bool quick = argc > 1 && !strcmp(argv[1], "quick");
@@ -458,6 +768,10 @@ int main(int argc, char **argv)
     }
     int fails = 0;
     for (const Case &c : cases) fails += run_case(c);
+    fails += run_jobs("jobs: plain sequence", 0);
+    fails += run_jobs("jobs: a launch that ends with a job", 1);
+    fails += run_jobs("jobs: idle limit, new launch", 2);
+    fails += run_jobs("jobs: forced give-up drains", 3);
     printf("%s (%d failing case%s)\n", fails ? "FAIL" : "PASS", fails, fails == 1 ? "" : "s");
     return fails ? 1 : 0;
 }

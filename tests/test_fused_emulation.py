@@ -18,3 +18,8 @@ def test_fused_kernel_body_bit_exact_under_asan():
     assert r.returncode == 0, r.stdout + r.stderr
     assert "PASS" in r.stdout and "MISMATCH" not in r.stdout
     assert r.stdout.count("bit-exact") >= 10
+    # round 3: the JOB protocol of the resident launch (fused_body.h "jobs"), every block a thread running the device's own
+    # protocol functions: a sequence of jobs whose tile -> block mapping changes, a launch that ends with a job, a launch that
+    # leaves on its idle limit and is started again, and a forced give-up that must drain and leave the initial condition intact
+    assert r.stdout.count("bit-exact (jobs)") == 3
+    assert "launch drained, initial condition intact" in r.stdout

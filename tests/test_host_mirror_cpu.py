@@ -209,3 +209,61 @@ def test_action_sequence_hands_the_abi_what_the_per_action_loop_does():
     for k in range(n):   # rows k*steps .. (k+1)*steps of the whole trace; neighbours share their boundary row
         assert sigs[k][0, 0] == 3 * k * steps and sigs[k][-1, 0] == 3 * (k + 1) * steps
     assert np.array_equal(b.signal, sigs[-1])
+
+
+def test_generate_episode_pipelines_only_policies_that_say_they_do_not_read_the_state():
+    """the reference's loop (src/data.jl:22-27) is strictly sequential; two actions in flight are only valid for a
+    policy that does not look at the wave state.  The default depth follows the policy's own `reads_state` attribute
+    (RandomDesignPolicy: False); an exception in a step leaves nothing pending in the env."""
+    import waves_jl_amd as w
+
+    class FakeEnv:
+        def __init__(self, fail_at=None):
+            self.actions, self.integration_steps, self.time_step, self.return_fields = 4, 20, 0, False
+            self.log, self.signal, self._pending, self.fail_at = [], np.zeros((21, 3), np.float32), [], fail_at
+
+        def is_terminated(self):
+            return self.time_step >= self.actions * self.integration_steps
+
+        def reset(self):
+            self.time_step = 0
+
+        def build_tspan(self):
+            return np.arange(21, dtype=np.float32)
+
+        def step_begin(self, a):
+            if self.fail_at is not None and len([x for x in self.log if x == "b"]) == self.fail_at:
+                raise RuntimeError("boom")
+            self.log.append("b")
+            self._pending.append(a)
+            self.time_step += self.integration_steps
+
+        def step_end(self):
+            self.log.append("e")
+            self._pending.pop(0)
+
+    class StatePolicy:          # says nothing: assumed to read the state
+        def __call__(self, env):
+            assert not env._pending, "policy called while an action is pending"
+            return 0
+
+    class BlindPolicy:
+        reads_state = False
+
+        def __call__(self, env):
+            return 0
+
+    env = FakeEnv()
+    w.generate_episode(StatePolicy(), env)
+    assert "".join(env.log) == "bebebebe"
+    env = FakeEnv()
+    w.generate_episode(BlindPolicy(), env)
+    assert "".join(env.log) == "bbebebee"
+    env = FakeEnv()
+    w.generate_episode(BlindPolicy(), env, in_flight=1)
+    assert "".join(env.log) == "bebebebe"
+    assert w.RandomDesignPolicy.reads_state is False
+    env = FakeEnv(fail_at=2)
+    with pytest.raises(RuntimeError):
+        w.generate_episode(BlindPolicy(), env)
+    assert not env._pending and env.return_fields is False

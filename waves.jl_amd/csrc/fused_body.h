@@ -134,9 +134,9 @@ struct JobMail {                 // pinned host memory; written by the host, rea
 };
 struct JobBack {                 // pinned host memory; written by the device
     unsigned done;               // number of the newest job whose outputs (state, frames, trace rows) are complete
-    unsigned status;             // JOBS_*: why the launch has left (JOBS_RUNNING while it has not)
-    unsigned exit_seq;           // the job the launch was waiting for / working on when it left
-    unsigned pad[13];
+    unsigned status[2];          // [launch]: JOBS_*: why that launch has left (JOBS_RUNNING while it has not)
+    unsigned exit_seq[2];        // [launch]: the job it was waiting for / working on when it left
+    unsigned pad[11];
     unsigned long long t_begin[2], t_end[2];  // [seq & 1]: 100 MHz device clock when the leader saw the job / saw it complete
     unsigned long long phase[2][8];           // diagnostic (FusedParams::back): the leader tile's clock at the phases of the job
     unsigned rowdone[JOB_MAX_TILES];          // [block]: number of the newest job whose trace rows of this block are in host memory
@@ -162,7 +162,7 @@ struct JobArgs {
     unsigned first_seq;          // the first job this launch serves
     unsigned idle_ticks;         // the leader leaves after this many 100 MHz ticks without a new bell
     int ntiles;
-    int pad;
+    int launch;                  // which of the two status words of JobBack is this launch's
 };
 
 // LDS image of one tile, carved out of one raw buffer (the kernel instantiates field sets with different RY over the
@@ -1193,8 +1193,8 @@ WV_HD int job_try_fetch(const JobArgs &a, unsigned seq, int lane)
     const int cmd = (got == seq && job_ld_agent(reinterpret_cast<const unsigned *>(&a.ctl->jobs[par].cmd)) == (unsigned)JOB_RUN) ? JOB_RUN : JOB_EXIT;
     if (lane == 0) {
         if (cmd != JOB_RUN) {
-            job_st_sys(&a.back->exit_seq, seq);
-            job_st_sys(&a.back->status, JOBS_EXIT_TOLD);
+            job_st_sys(&a.back->exit_seq[a.launch], seq);
+            job_st_sys(&a.back->status[a.launch], JOBS_EXIT_TOLD);
             job_drain();
         }
         job_st_agent64(reinterpret_cast<unsigned long long *>(&a.ctl->go[par]), (unsigned long long)seq | ((unsigned long long)(unsigned)cmd << 32));
@@ -1214,8 +1214,8 @@ WV_HD int job_leader_fetch(const JobArgs &a, unsigned seq, int lane)
         job_pause();
     }
     if (lane == 0) {
-        job_st_sys(&a.back->exit_seq, seq);
-        job_st_sys(&a.back->status, JOBS_EXIT_IDLE);
+        job_st_sys(&a.back->exit_seq[a.launch], seq);
+        job_st_sys(&a.back->status[a.launch], JOBS_EXIT_IDLE);
         job_drain();
         job_st_agent64(reinterpret_cast<unsigned long long *>(&a.ctl->go[seq & 1u]), (unsigned long long)seq | ((unsigned long long)(unsigned)JOB_EXIT << 32));
     }

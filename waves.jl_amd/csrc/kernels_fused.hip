@@ -528,8 +528,8 @@ __global__ __launch_bounds__(NW * 64, 4) void k_steps_resident(JobArgs a_)
         const int b = (int)blockIdx.x;
         if (!ok) {  // abandoned (block-uniform): tell the host why the launch is gone
             if (threadIdx.x == 0) {
-                job_st_sys(&a.back->exit_seq, seq);
-                job_st_sys(&a.back->status, JOBS_EXIT_ABORT);
+                job_st_sys(&a.back->exit_seq[a.launch], seq);
+                job_st_sys(&a.back->status[a.launch], JOBS_EXIT_ABORT);
             }
             return;
         }
@@ -554,8 +554,8 @@ __global__ __launch_bounds__(NW * 64, 4) void k_steps_resident(JobArgs a_)
         if (vote[0] != 0) {  // (cannot happen short of a fault: a block that got here has nothing left to wait for but the others' last stores)
             if (threadIdx.x == 0) {
                 __hip_atomic_store(p.abort, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                job_st_sys(&a.back->exit_seq, seq);
-                job_st_sys(&a.back->status, JOBS_EXIT_ABORT);
+                job_st_sys(&a.back->exit_seq[a.launch], seq);
+                job_st_sys(&a.back->status[a.launch], JOBS_EXIT_ABORT);
             }
             return;
         }
@@ -572,8 +572,8 @@ __global__ __launch_bounds__(NW * 64, 4) void k_steps_resident(JobArgs a_)
         if (b == 0 && threadIdx.x == 0) {
             job_st_sys64(&a.back->t_end[seq & 1u], job_clock());
             if (p.last) {
-                job_st_sys(&a.back->exit_seq, seq);
-                job_st_sys(&a.back->status, JOBS_EXIT_LAST);
+                job_st_sys(&a.back->exit_seq[a.launch], seq);
+                job_st_sys(&a.back->status[a.launch], JOBS_EXIT_LAST);
             }
             job_drain();
             job_st_sys(&a.back->done, seq);
@@ -702,19 +702,26 @@ struct FusedPlan {
     JobCtl *d_ctl = nullptr;
     int ctl_tiles = 0;            // tiles the flag arrays behind d_ctl were sized for
     unsigned seq = 0;             // jobs described so far (job numbers start at 1)
-    bool p_alive = false;         // a launch was started and has not been waited for
-    bool p_stays = false;         // ... and the newest job it was given lets it stay (FusedParams::last == 0)
-    int p_ntiles = 0;             // its grid
-    unsigned p_first = 0;         // the first job it serves
-    hipStream_t p_stream = nullptr;
-    hipEvent_t p_start = nullptr, p_stop = nullptr, p_up = nullptr;
+    // Launches: at most two are known at a time -- the newest, and the one before it while it still runs (a launch that ends
+    // with its job, FusedParams::last, is simply followed by the next call's launch in stream order; only a launch that STAYS
+    // has to be told to leave before anything else may use the stream).
+    struct Launch {
+        bool alive = false;       // started and not yet seen to have ended (its stop event not yet taken)
+        bool stays = false;       // the newest job it was given lets it stay (FusedParams::last == 0)
+        int ntiles = 0;
+        unsigned first = 0;       // the first job it serves
+        hipStream_t stream = nullptr;
+        hipEvent_t start = nullptr, stop = nullptr;
+    } L[2];
+    int cur_l = 0;                // the newest launch
+    hipEvent_t p_up = nullptr;
+    int job_launch[2] = {0, 0};       // per slot: the launch its resident call was given to
     int job_rows[2] = {0, 0};         // per slot: blocks of that call that write trace rows to host memory
     unsigned job_seq[2] = {0, 0};     // per slot: the job of the slot's resident call that has not been waited for (0: none)
     bool job_keep[2] = {false, false};  // ... and whether the launch was asked to stay after it
     double last_job_ms = 0.0;     // in-kernel duration of the job waited for last
-    double last_launch_ms = 0.0;  // duration (HIP events) and jobs of the launch retired last
+    double last_launch_ms = 0.0;  // duration (HIP events) and jobs of the launch that ended last
     int last_launch_jobs = 0;
-    unsigned p_jobs_done_at_launch = 0;
     long n_launches = 0, n_jobs = 0, n_handed = 0;  // diagnostics (WAVES_AMD_HOSTPROF): launches, jobs, jobs handed to a launch that was there
     std::vector<double> job_ms;   // in-kernel duration of the jobs waited for since the last fused_job_stats reset
 };
@@ -770,7 +777,7 @@ void fused_destroy(FusedPlan *p)
     if (p->mail) (void)hipHostFree(p->mail);
     if (p->back) (void)hipHostFree(p->back);
     if (p->d_ctl) (void)hipFree(p->d_ctl);
-    for (hipEvent_t e : {p->p_start, p->p_stop, p->p_up})
+    for (hipEvent_t e : {p->L[0].start, p->L[0].stop, p->L[1].start, p->L[1].stop, p->p_up})
         if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < 2; ++k) {
         if (p->d_tiles[k]) (void)hipFree(p->d_tiles[k]);
@@ -1093,10 +1100,12 @@ static bool jobs_ensure(FusedPlan *pl, int ntiles)
         if (hipHostMalloc((void **)&pl->back, sizeof(JobBack), hipHostMallocDefault) != hipSuccess) return false;
         memset((void *)pl->back, 0, sizeof(JobBack));
     }
-    if (!pl->p_start && (hipEventCreate(&pl->p_start) != hipSuccess || hipEventCreate(&pl->p_stop) != hipSuccess ||
-                         hipEventCreateWithFlags(&pl->p_up, hipEventDisableTiming) != hipSuccess))
-        return false;
-    if (!pl->d_ctl || ntiles > pl->ctl_tiles) {  // (never while a launch is alive: the caller retires it when the tiling changes)
+    if (!pl->p_up) {
+        for (FusedPlan::Launch &l : pl->L)
+            if (hipEventCreate(&l.start) != hipSuccess || hipEventCreate(&l.stop) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&pl->p_up, hipEventDisableTiming) != hipSuccess) return false;
+    }
+    if (!pl->d_ctl || ntiles > pl->ctl_tiles) {  // (never while a launch is alive: the caller waits for them when the tiling changes)
         if (pl->d_ctl) (void)hipFree(pl->d_ctl);
         pl->d_ctl = nullptr;
         const int cap = std::max(ntiles, 1024);
@@ -1107,43 +1116,44 @@ static bool jobs_ensure(FusedPlan *pl, int ntiles)
     return true;
 }
 
-// A launch is on the device and has not said that it is leaving.  (One that has said so may still be draining; work
-// enqueued on its stream is ordered behind it either way.)
+static unsigned back_status(FusedPlan *pl, int l) { return __atomic_load_n(&pl->back->status[l], __ATOMIC_ACQUIRE); }
+static unsigned back_done(FusedPlan *pl) { return __atomic_load_n(&pl->back->done, __ATOMIC_ACQUIRE); }
+
+// The newest launch is on the device, stays there after its jobs, and has not said that it is leaving: it owns the stream
+// (anything enqueued there would wait out its idle limit) and takes further jobs.
 bool fused_persist_alive(FusedPlan *pl)
 {
-    if (!pl->p_alive || !pl->p_stays) return false;  // (a launch that ends with its job blocks nothing and takes no further job)
-    return __atomic_load_n(&pl->back->status, __ATOMIC_ACQUIRE) == JOBS_RUNNING;
+    const FusedPlan::Launch &l = pl->L[pl->cur_l];
+    return l.alive && l.stays && back_status(pl, pl->cur_l) == JOBS_RUNNING;
 }
 
-// the launch has ended (its stop event has fired): bookkeeping
-static void jobs_reap(FusedPlan *pl)
+// launch l has ended (its stop event has fired): bookkeeping
+static void jobs_reap(FusedPlan *pl, int l)
 {
-    if (!pl->p_alive) return;
+    FusedPlan::Launch &L = pl->L[l];
+    if (!L.alive) return;
     float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, pl->p_start, pl->p_stop) == hipSuccess) {
+    if (hipEventElapsedTime(&ms, L.start, L.stop) == hipSuccess) {
         pl->last_launch_ms = ms;
-        pl->last_launch_jobs = (int)(__atomic_load_n(&pl->back->done, __ATOMIC_ACQUIRE) - pl->p_jobs_done_at_launch);
+        // the jobs it completed: from its first job to the last one done before the next launch's first (or to `done`)
+        const unsigned upto = (l != pl->cur_l && pl->L[pl->cur_l].alive) ? pl->L[pl->cur_l].first - 1 : back_done(pl);
+        pl->last_launch_jobs = job_reached(upto, L.first) ? (int)(upto - L.first + 1) : 0;
     } else {
         (void)hipGetLastError();
     }
-    pl->p_alive = false;
+    L.alive = false;
 }
 
-// Make the launch leave (after the jobs it has been given) and wait until it has.  Everything that wants the context's
-// stream for itself goes through here first: work enqueued behind a launch that idles would wait out its idle limit.
-int fused_retire(FusedPlan *pl)
+// wait (polling first: a launch that has said it is leaving is microseconds from its end) until launch l has ended
+static int jobs_join(FusedPlan *pl, int l)
 {
-    if (!pl || !pl->p_alive) return 0;
-    if (pl->p_stays && __atomic_load_n(&pl->back->status, __ATOMIC_ACQUIRE) == JOBS_RUNNING) {
-        pl->seq++;
-        FusedParams &d = pl->mail->desc[pl->seq & 1u];
-        d = FusedParams{};
-        d.seq = pl->seq;
-        d.cmd = JOB_EXIT;
-        __atomic_store_n(&pl->mail->bell, pl->seq, __ATOMIC_RELEASE);
-    }
-    const hipError_t e = hipEventSynchronize(pl->p_stop);
-    jobs_reap(pl);
+    FusedPlan::Launch &L = pl->L[l];
+    if (!L.alive) return 0;
+    hipError_t e;
+    unsigned n = 0;
+    while ((e = hipEventQuery(L.stop)) == hipErrorNotReady && ++n < (1u << 20)) {}
+    if (e == hipErrorNotReady) e = hipEventSynchronize(L.stop);
+    jobs_reap(pl, l);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return 1;
@@ -1151,8 +1161,26 @@ int fused_retire(FusedPlan *pl)
     return 0;
 }
 
-// Would fused_prepare / fused_try_resident enqueue anything on the context's stream for such a call?  (Then a live launch
-// has to be retired first: see fused_retire.)
+// Make a launch that stays leave (after the jobs it has been given) and wait until every launch has ended.  Everything that
+// wants the context's stream for itself goes through here first.
+int fused_retire(FusedPlan *pl)
+{
+    if (!pl) return 0;
+    if (fused_persist_alive(pl)) {
+        pl->seq++;
+        FusedParams &d = pl->mail->desc[pl->seq & 1u];
+        d = FusedParams{};
+        d.seq = pl->seq;
+        d.cmd = JOB_EXIT;
+        __atomic_store_n(&pl->mail->bell, pl->seq, __ATOMIC_RELEASE);
+    }
+    int rc = jobs_join(pl, pl->cur_l ^ 1);
+    rc |= jobs_join(pl, pl->cur_l);
+    return rc;
+}
+
+// Would fused_prepare / fused_try_resident enqueue anything on the context's stream for such a call?  (Then a launch that
+// stays has to be retired first: see fused_retire.)
 bool fused_needs_stream(FusedPlan *pl, bool capture, const float *G, int out2_idx)
 {
     if (pl->aux_state < 0) return true;
@@ -1164,11 +1192,14 @@ bool fused_needs_stream(FusedPlan *pl, bool capture, const float *G, int out2_id
     return false;
 }
 
-static int jobs_launch(FusedPlan *pl, unsigned first_seq, hipStream_t s)
+// a new launch, behind whatever is on `s` (an earlier launch that ends with its job included)
+static int jobs_launch(FusedPlan *pl, unsigned first_seq, int ntiles, hipStream_t s)
 {
+    const int l = pl->cur_l ^ 1;
+    if (jobs_join(pl, l) != 0) return 1;  // (the launch before the previous one: long gone)
     // (leftovers of an earlier launch in the go words -- "job n: leave" -- must not be taken for this launch's answer)
     if (hipMemsetAsync(pl->d_ctl->go, 0, sizeof(pl->d_ctl->go), s) != hipSuccess) return 1;
-    __atomic_store_n(&pl->back->status, (unsigned)JOBS_RUNNING, __ATOMIC_RELEASE);
+    __atomic_store_n(&pl->back->status[l], (unsigned)JOBS_RUNNING, __ATOMIC_RELEASE);
     JobArgs a{};
     a.mail = pl->mail;
     a.back = pl->back;
@@ -1176,7 +1207,8 @@ static int jobs_launch(FusedPlan *pl, unsigned first_seq, hipStream_t s)
     a.first_seq = first_seq;
     const unsigned long long ticks = (unsigned long long)pl->idle_us * 100ull;
     a.idle_ticks = (unsigned)std::min<unsigned long long>(ticks, 0x7fffffffull);
-    a.ntiles = pl->p_ntiles;
+    a.ntiles = ntiles;
+    a.launch = l;
     void *args[1] = {&a};
     // A plain launch: the grid is at most the number of blocks the device holds at once (resident_capacity, from the
     // occupancy query -- the same number a cooperative launch would check it against), and an ordinary launch has the same
@@ -1184,23 +1216,26 @@ static int jobs_launch(FusedPlan *pl, unsigned first_seq, hipStream_t s)
     // every other stream of the process.  The launch carries its two events itself (hipExtLaunchKernel: they take the
     // kernel's own start and end timestamps).
     static const bool coop = getenv("WAVES_AMD_COOP") && atoi(getenv("WAVES_AMD_COOP")) != 0;
+    FusedPlan::Launch &L = pl->L[l];
     hipError_t e;
     if (coop) {
-        (void)hipEventRecord(pl->p_start, s);
-        e = hipLaunchCooperativeKernel(resident_ptr(pl), dim3((unsigned)pl->p_ntiles), dim3(512), args, 0, s);
-        if (e == hipSuccess) (void)hipEventRecord(pl->p_stop, s);
+        (void)hipEventRecord(L.start, s);
+        e = hipLaunchCooperativeKernel(resident_ptr(pl), dim3((unsigned)ntiles), dim3(512), args, 0, s);
+        if (e == hipSuccess) (void)hipEventRecord(L.stop, s);
     } else {
-        e = hipExtLaunchKernel(resident_ptr(pl), dim3((unsigned)pl->p_ntiles), dim3(512), args, 0, s, pl->p_start, pl->p_stop, 0);
+        e = hipExtLaunchKernel(resident_ptr(pl), dim3((unsigned)ntiles), dim3(512), args, 0, s, L.start, L.stop, 0);
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return -1;
     }
-    pl->p_alive = true;
+    L.alive = true;
+    L.stays = false;  // (the caller says)
+    L.ntiles = ntiles;
+    L.first = first_seq;
+    L.stream = s;
+    pl->cur_l = l;
     pl->n_launches++;
-    pl->p_first = first_seq;
-    pl->p_stream = s;
-    pl->p_jobs_done_at_launch = first_seq - 1;
     return 0;
 }
 
@@ -1213,16 +1248,16 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
     const size_t nt = pl->hp.tiles.size();
     if (nsteps < 2 || (int)nt > resident_capacity(pl) || (int)nt > JOB_MAX_TILES) return -1;
     bool alive = fused_persist_alive(pl);
-    if (alive && ((int)nt != pl->p_ntiles || s != pl->p_stream)) {  // (a new tiling: new grid)
+    // (a new tiling: new grid; no copy stream: the uploads would queue behind the launch they are meant for)
+    if (alive && ((int)nt != pl->L[pl->cur_l].ntiles || s != pl->L[pl->cur_l].stream || up == s)) {
         if (fused_retire(pl)) return 1;
         alive = false;
     }
-    if (alive && up == s) {  // (no copy stream: the uploads would queue behind the launch they are meant for)
-        if (fused_retire(pl)) return 1;
-        alive = false;
+    if (!alive && pl->L[pl->cur_l].alive && pl->L[pl->cur_l].stays) {  // it has said it is leaving (idle limit): take its end
+        if (jobs_join(pl, pl->cur_l)) return 1;
     }
-    if (pl->p_alive && !alive) {  // it has said it is leaving (idle, told): wait for the rest of it
-        if (fused_retire(pl)) return 1;
+    if (!pl->d_ctl || (int)nt > pl->ctl_tiles) {
+        if (fused_retire(pl)) return 1;  // (nothing alive may hold the control block that is about to be replaced)
     }
     if (!jobs_ensure(pl, (int)nt)) {
         (void)hipGetLastError();
@@ -1303,7 +1338,7 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
             return 1;
         }
         if (!fused_persist_alive(pl)) {  // it left meanwhile (idle limit)
-            if (fused_retire(pl)) return 1;
+            if (jobs_join(pl, pl->cur_l)) return 1;
             alive = false;
         }
     }
@@ -1314,8 +1349,7 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
     pl->mail->desc[pl->seq & 1u] = p;
     __atomic_store_n(&pl->mail->bell, pl->seq, __ATOMIC_RELEASE);
     if (!alive) {
-        pl->p_ntiles = (int)nt;
-        const int rc = jobs_launch(pl, pl->seq, s);
+        const int rc = jobs_launch(pl, pl->seq, (int)nt, s);
         if (rc != 0) {
             pl->seq--;  // (nobody has seen the description)
             __atomic_store_n(&pl->mail->bell, pl->seq, __ATOMIC_RELEASE);
@@ -1323,59 +1357,59 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
             return rc;
         }
     }
+    pl->L[pl->cur_l].stays = p.last == 0;
     pl->tag_base += (unsigned)nsteps;
     pl->n_jobs++;
     pl->n_handed += alive ? 1 : 0;
     pl->job_seq[slot] = pl->seq;
+    pl->job_launch[slot] = pl->cur_l;
     pl->job_keep[slot] = p.last == 0;
     pl->job_rows[slot] = ef.signal ? std::min(nsteps + 1, (int)nt) : 0;
-    pl->p_stays = p.last == 0;
     pl->abort_pending[slot] = true;
     return 0;
 }
 
-// Wait for the slot's resident call.  0: done; 2: the launch gave the call up -- its initial condition is intact (the final state has a buffer of its own)
-// and the caller runs it again with the single-step kernels (fused_rerun_steps); 1: HIP error.  A launch that left on its
-// idle limit before it saw the job is started again here.
+// Wait for the slot's resident call.  0: done; 2: the launch gave the call up -- its initial condition is intact (the final
+// state has a buffer of its own) and the caller runs it again with the single-step kernels (fused_rerun_steps); 1: HIP
+// error.  A launch that left on its idle limit before it saw the job is started again here.
 int fused_job_wait(FusedPlan *pl, int slot, hipStream_t s)
 {
     const unsigned want = pl->job_seq[slot];
     if (!want) return 0;
     pl->job_seq[slot] = 0;
     pl->abort_pending[slot] = false;
-    unsigned spins = 0;
     const int writers = pl->job_rows[slot];  // blocks that put trace rows into host memory (0: no trace wanted)
     pl->job_rows[slot] = 0;
+    int l = pl->job_launch[slot];
     auto complete = [&]() {
-        if (!job_reached(__atomic_load_n(&pl->back->done, __ATOMIC_ACQUIRE), want)) return false;
+        if (!job_reached(back_done(pl), want)) return false;
         for (int k = writers - 1; k >= 0; --k)
             if (!job_reached(__atomic_load_n(&pl->back->rowdone[k], __ATOMIC_ACQUIRE), want)) return false;
         return true;
     };
+    unsigned spins = 0;
     for (;;) {
         if (complete()) break;
         if ((++spins & 1023u) != 0) continue;
         // not done yet: is the launch still there?
-        if (pl->p_alive && hipEventQuery(pl->p_stop) == hipSuccess) {
-            if (complete()) break;
-            const unsigned why = __atomic_load_n(&pl->back->status, __ATOMIC_ACQUIRE);
-            jobs_reap(pl);
-            if (why == JOBS_EXIT_ABORT) return 2;
-            // left on its idle limit (or told to) without having seen this job: the description and the bell are still
-            // there -- a new launch takes over from this job on
-            const unsigned done = __atomic_load_n(&pl->back->done, __ATOMIC_ACQUIRE);
-            const int rc = jobs_launch(pl, done + 1, s);
-            if (rc != 0) return 1;
-        } else if (!pl->p_alive) {
-            const unsigned why = __atomic_load_n(&pl->back->status, __ATOMIC_ACQUIRE);
-            if (why == JOBS_EXIT_ABORT) return 2;
-            const unsigned done = __atomic_load_n(&pl->back->done, __ATOMIC_ACQUIRE);
-            if (complete()) break;
-            const int rc = jobs_launch(pl, done + 1, s);
-            if (rc != 0) return 1;
-        } else {
+        FusedPlan::Launch &L = pl->L[l];
+        const bool ended = !L.alive || hipEventQuery(L.stop) == hipSuccess;
+        if (!ended) {
             (void)hipGetLastError();  // (hipErrorNotReady)
+            continue;
         }
+        if (complete()) break;
+        const unsigned why = back_status(pl, l);
+        jobs_reap(pl, l);
+        if (why == JOBS_EXIT_ABORT) return 2;
+        // it left on its idle limit (or was told to) without having seen this job: the description and the bell are still
+        // there -- a new launch takes over from the first job that is not done
+        if (l == pl->cur_l) {
+            const int rc = jobs_launch(pl, back_done(pl) + 1, L.ntiles, s);
+            if (rc != 0) return 1;
+            pl->L[pl->cur_l].stays = pl->job_keep[slot];
+        }
+        l = pl->cur_l;  // (or: a newer launch exists already and will get to it)
     }
     // in-kernel duration of the job (the leader's 100 MHz stamps)
     const unsigned par = want & 1u;
@@ -1388,26 +1422,15 @@ int fused_job_wait(FusedPlan *pl, int slot, hipStream_t s)
                 (double)(t1 - t0) * 0.01, prev_end ? (double)((long long)(t0 - prev_end)) * 0.01 : 0.0);
         prev_end = t1;
         const unsigned long long *ph = pl->back->phase[par];
-        fprintf(stderr, "    phases (us after begin): go seen by all %.2f | state loaded %.2f | steps done %.2f | (unused) %.2f | stores drained %.2f | "
+        fprintf(stderr, "    phases (us after begin): go seen by all %.2f | state loaded %.2f | steps done %.2f | stores drained %.2f | "
                         "barrier B %.2f | end %.2f\n", (double)(long long)(ph[0] - t0) * 0.01, (double)(long long)(ph[1] - t0) * 0.01,
-                (double)(long long)(ph[2] - t0) * 0.01, (double)(long long)(ph[3] - t0) * 0.01, (double)(long long)(ph[4] - t0) * 0.01,
-                (double)(long long)(ph[5] - t0) * 0.01, (double)(long long)(t1 - t0) * 0.01);
+                (double)(long long)(ph[2] - t0) * 0.01, (double)(long long)(ph[4] - t0) * 0.01, (double)(long long)(ph[5] - t0) * 0.01,
+                (double)(long long)(t1 - t0) * 0.01);
     }
     pl->last_job_ms = ms;
     if (pl->job_ms.size() < (size_t)1 << 16) pl->job_ms.push_back(ms);
-    if (!pl->job_keep[slot]) {  // the launch ended with this job: take its stop event so that its duration is known
-        if (pl->p_alive) {       // (polled: the kernel is a few microseconds from its end, a blocking wait costs far more)
-            hipError_t e;
-            unsigned n = 0;
-            while ((e = hipEventQuery(pl->p_stop)) == hipErrorNotReady && ++n < (1u << 22)) {}
-            if (e == hipErrorNotReady) e = hipEventSynchronize(pl->p_stop);
-            jobs_reap(pl);
-            if (e != hipSuccess) {
-                (void)hipGetLastError();
-                return 1;
-            }
-        }
-    }
+    // a launch that ended with this job: take its stop event (it is microseconds away) so that its duration is known
+    if (!pl->job_keep[slot] && pl->L[l].alive && !pl->L[l].stays && jobs_join(pl, l) != 0) return 1;
     return 0;
 }
 
@@ -1416,10 +1439,8 @@ int fused_job_wait(FusedPlan *pl, int slot, hipStream_t s)
 // well still be there at the next call
 void fused_gave_up(FusedPlan *pl, hipStream_t s)
 {
-    if (pl->p_alive) {
-        (void)hipEventSynchronize(pl->p_stop);
-        jobs_reap(pl);
-    }
+    (void)jobs_join(pl, pl->cur_l ^ 1);
+    (void)jobs_join(pl, pl->cur_l);
     (void)hipMemsetAsync(pl->d_abort, 0, sizeof(int), s);
     pl->use_resident = false;
     for (int k = 0; k < 2; ++k) {

@@ -127,12 +127,14 @@ def prepare_data(ep, horizon: int):
 
 
 def generate_episode(policy, env, *, reset: bool = True, with_states: bool = False, verbose: bool = False,
-                     in_flight: int = 2, per_launch: int | None = None) -> Episode:
+                     in_flight: int | None = None, per_launch: int | None = None) -> Episode:
     """generate_episode!(policy, env)  src/data.jl:12-33.  `with_states=True` records `state(env)` before every action
     like the reference does (the observation is resized on the device: 256 KB per action); the default skips it, which is
-    all the energy-trace benchmarks need.  Without states nothing in the loop reads the wave, so two actions are kept in
-    flight (`in_flight=2`: the host prepares action k+1 while action k runs; valid for policies that do not look at the
-    wave state, like the reference's RandomDesignPolicy); `in_flight=1` is the plain sequential loop.
+    all the energy-trace benchmarks need.  `in_flight=2` keeps two actions in flight (the host prepares action k+1 while
+    action k runs): policy(env) for action k+1 is then called while action k is still pending, so it is only valid for
+    policies that do not look at the wave state.  The default (`in_flight=None`) therefore is the reference's strictly
+    sequential loop (src/data.jl:22-27) UNLESS the policy itself says `reads_state = False`, as RandomDesignPolicy (which
+    only samples its action space, src/env.jl:151-157) does; `in_flight=1` forces the sequential loop.
     `per_launch=n` hands n actions at a time to ONE device call (WaveEnv.steps_begin, wv_set_design_sequence; again for
     policies that do not read the wave state): the launch start-up and the gap between launches are paid once per n
     actions, and with `with_states=True` the frames of every action are kept on the device, so that the episode holds
@@ -162,6 +164,8 @@ def generate_episode(policy, env, *, reset: bool = True, with_states: bool = Fal
         return Episode(s, a, t, y)
     keep = env.return_fields
     env.return_fields = False  # the rollout discards the returned fields (src/data.jl:27)
+    if in_flight is None:
+        in_flight = 2 if getattr(policy, "reads_state", True) is False else 1
     depth = 1 if with_states else max(1, min(2, int(in_flight)))
     pending = 0
     try:
@@ -185,4 +189,12 @@ def generate_episode(policy, env, *, reset: bool = True, with_states: bool = Fal
             y.append(np.array(env.signal))
     finally:
         env.return_fields = keep
+        while pending:   # (an exception in the policy or in a step: nothing stays pending in the env or the context)
+            pending -= 1
+            try:
+                env.step_end()
+            except Exception:
+                if getattr(env, "_pending", None):
+                    env._pending.clear()
+                break
     return Episode(s, a, t, y)

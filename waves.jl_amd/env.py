@@ -117,6 +117,10 @@ class WaveEnv:
             raise ValueError("steps_begin: trajectories are per action -- use step_begin / step_end")
         if self.integration_steps < 2 * FRAMESKIP:
             raise IndexError("BoundsError: sol[:, :, :, end-20:10:end] needs integration_steps >= 20 (src/env.jl:116)")
+        if keep_frames and self.integration_steps <= 2 * FRAMESKIP:
+            # (the first kept frame of an action would be the state the action STARTS from, which no step of the one launch
+            # writes; the per-action loop copies it -- wv_integrate_begin says the same for capture_frames == 2)
+            raise ValueError("steps_begin(keep_frames=True) needs integration_steps > 20: use the per-action loop (step_begin / step_end)")
         tspans, interps, designs = [], [], [self.design]
         for action in actions:
             tspan = self.build_tspan()
@@ -258,6 +262,8 @@ def reward(env):
 
 class RandomDesignPolicy:
     """src/env.jl:151-157."""
+
+    reads_state = False   # it only samples its action space: rollouts may keep two of its actions in flight (generate_episode)
 
     def __init__(self, a_space: DesignSpace, rng=None):
         self.a_space = a_space
