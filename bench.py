@@ -76,7 +76,34 @@ def cpu_baseline(n_steps: int):
         nth = len(os.sched_getaffinity(0))
     except Exception:
         nth = os.cpu_count() or 1
+    nvis = nth
     nth = min(nth, 16)  # the CPU share of a one-GPU box (its host may show hundreds of cores it will not give us)
+    # BASELINE config 1 (the CPU-path configuration: TwoDim(15, 256), single Gaussian source at (-10, 0), no design, 100
+    # integration steps), same port, one core
+    dim1 = wo.TwoDim.from_size(15.0, 256)
+    G1 = wo.build_normal(wo.build_grid(dim1), np.array([[-10.0, 0.0]]), np.array([0.3]), np.array([1.0]))
+    sx1 = wo.build_pml_profile(dim1.x, 2.0, 20000.0)
+    ts1 = wo.build_tspan(0.0, 1e-5, 100)
+    t0 = time.perf_counter()
+    co.integrate(dim1.x, dim1.y, sx1, sx1, wo.WATER, 1e-5, np.zeros((12, 256, 256), f32), ts1, G=wo.to_abi(G1), freq=1000.0, nthreads=1)
+    dt1 = time.perf_counter() - t0
+    out["config1_256"] = {"value": round(256 * 256 * 100 / dt1 / 1e6, 3), "unit": "Mcell-updates/s", "cores": 1, "kind": "port",
+                          "sample": f"all 100 steps of BASELINE config 1 ({dt1:.2f} s), oracle/waves_oracle.c single thread"}
+    # R1 of SURVEY 8d: the reference-STRUCTURE restatement (numpy + scipy.sparse gradient matrices, the same temporaries,
+    # concats and four wave-speed assemblies per step as the Julia source), one core, a bounded sample of both configurations
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import r1_baseline
+        r1 = r1_baseline.bounded_sample(10, 2)
+        out["r1_reference_structure"] = {"unit": "Mcell-updates/s", "cores": 1, "kind": "port (numpy + scipy.sparse, tools/r1_baseline.py)",
+                                         **r1}
+    except Exception as e:  # (scipy missing on some box: say so instead of failing the bench line)
+        out["r1_reference_structure"] = {"error": repr(e)}
+    try:
+        model = next((l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "?")
+    except Exception:
+        model = "?"
+    out["host"] = {"cpu": model, "cores_visible": nvis}
     if nth > 1:
         st = np.zeros((12, N_GRID, N_GRID), f32)
         ts2 = wo.build_tspan(0.0, 1e-5, 2 * n_steps)
@@ -276,6 +303,7 @@ def timed_rollout(env, policy, n_actions, in_flight=2):
     """n_actions x env(policy(env)) with two actions in flight (w.rollout_pipelined spelled out to collect the timings);
     in_flight = 1 is the plain `env(action)` loop."""
     sigs, kern_ms, launches, dev_ms = [], 0.0, 0, 0.0
+    job_us = timed_rollout.job_us = []
 
     def end():
         nonlocal kern_ms, launches, dev_ms
@@ -285,6 +313,7 @@ def timed_rollout(env, policy, n_actions, in_flight=2):
         kern_ms += t["step_kernel_ms"]
         launches += t["step_kernel_launches"]
         dev_ms += t["total_ms"]
+        job_us.append(t["step_kernel_ms"] * 1e3 / max(t["step_kernel_launches"], 1))
 
     for k in range(n_actions):
         env.step_begin(policy(env))
@@ -321,6 +350,40 @@ def side_config(w, ds, dev, impl, grid, pml_width, actions, traffic_tab):
             "frac": round(B_ALG * units / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "whole_job_frac": round(B_ALG * actions * STEPS_PER_ACTION * cells / dt / (HBM_PEAK_GBS * 1e9), 4),
             "traffic": traffic_tab.get(key) if (grid == N_GRID or pml_width == 2.0) else None}
+
+
+def sweep_config(w, ds, dev, impl, grid, pml_width, nsteps, traffic_tab):
+    """BASELINE config 4 as stated: the 2048^2 grid, one PML width of the sweep, ONE call of 500 integration steps (never `value`)."""
+    import torch
+    dim = w.TwoDim(15.0, grid)
+    src = w.RandomPosGaussianSource(w.build_grid(dim), [[-10.0, -10.0]], [[-10.0, 10.0]], [0.3], [1.0], 1000.0,
+                                    rng=np.random.default_rng(77))
+    env = w.WaveEnv(dim, design_space=ds, source=src, integration_steps=nsteps, actions=4, device=dev, impl=impl,
+                    rng=np.random.default_rng(78), return_fields=False, pml_width=pml_width)
+    policy = w.RandomDesignPolicy(env.action_space(), np.random.default_rng(79))
+    env.reset()
+    env(policy(env))        # warm-up: allocations, the step graph of this shape
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    env(policy(env))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tim = env.ctx.timing()
+    resident = bool(tim["resident"])
+    cells = grid * grid
+    launches = max(tim["step_kernel_launches"], 1)
+    avg_ms = tim["step_kernel_ms"] / launches
+    units = cells * (nsteps if resident else 1)
+    sig = env.signal
+    env.ctx.close()
+    return {"workload": f"TwoDim(15.0f0, {grid}) + triple-ring design_space, pml_width {pml_width}, ONE call of {nsteps} integration steps",
+            "kernel": "k_steps_resident" if resident else "k_step_fused",
+            "value": round(nsteps * cells / dt / 1e6, 2), "unit": "Mcell-updates/s", "ms_per_call": round(dt * 1e3, 3),
+            "avg_kernel_us": round(avg_ms * 1e3, 3), "steps_per_launch": nsteps if resident else 1,
+            "frac": round(B_ALG * units / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "whole_job_frac": round(B_ALG * nsteps * cells / dt / (HBM_PEAK_GBS * 1e9), 4),
+            "energy_end": [float(v) for v in sig[-1]],
+            "traffic": traffic_tab.get(f"fused_{grid}") if pml_width == 2.0 else None}
 
 
 def main():
@@ -407,6 +470,8 @@ def main():
     gc.collect()
     gc.freeze()
 
+    for en in envs:   # the warm-up's resident launch leaves here: the timed region starts (and pays for) its own launch
+        en.ctx.synchronize()
     wd.barrier()
     sync_device()
     t0 = time.perf_counter()
@@ -454,6 +519,18 @@ def main():
             avg_ms = kern_ms / kern_launches
         else:                                      # staged path: whole call / launches
             avg_ms = dev_ms / (args.steps * E * launches_per_action)
+        # The resident kernel serves the whole timed region as ONE launch (a job per action; ctx.synchronize() above made it
+        # leave): its duration by the HIP events the launch carries, divided by the actions it served, is the average launch
+        # time per action -- idle time between actions, if the host was ever late, included; rocprofv3 sees the same dispatch.
+        # (If the launch left on its idle limit in between, several launches served the region: then the kernel's own clock
+        # stamps around every job, summed, are used instead.)
+        launch_info = None
+        job_us = sorted(getattr(timed_rollout, "job_us", []) or [])
+        if resident and E == 1 and tim.get("launch_jobs", 0) == args.steps and tim.get("launch_ms", 0.0) > 0.0:
+            avg_ms = tim["launch_ms"] / tim["launch_jobs"]
+            launch_info = {"launches_in_timed_region": 1, "actions_served": tim["launch_jobs"], "launch_ms": round(tim["launch_ms"], 4)}
+        elif resident and E == 1:
+            launch_info = {"launches_in_timed_region": "more than one (idle limit)", "actions_served": tim.get("launch_jobs", 0)}
         env.ctx.set_profiling(True)
         kms, launches = 0.0, 0
         for _ in range(2):
@@ -507,6 +584,13 @@ def main():
                                            if traffic is not None else None,
                          "kernel": kname,
                          "avg_kernel_us": round(avg_ms * 1e3, 3), "event_bracketed_kernel_us": round(bracketed_us, 3),
+                         "avg_kernel_us_is": ("HIP-event duration of the one resident launch that served the timed region / actions served"
+                                              if launch_info and launch_info["launches_in_timed_region"] == 1 else
+                                              "mean over the timed region of the per-call durations the library reports"),
+                         "launch": launch_info,
+                         "job_us": ({"min": round(job_us[0], 2), "median": round(job_us[len(job_us) // 2], 2), "max": round(job_us[-1], 2),
+                                     "n": len(job_us), "what": "per action, the kernel's own 100 MHz clock: job seen -> state, frames, trace complete"}
+                                    if job_us and resident else None),
                          "algorithmic_bytes_per_launch": alg_bytes, "steps_per_launch": STEPS_PER_ACTION if resident else 1,
                          "whole_job_frac": round(B_ALG * value * 1e6 / world / (HBM_PEAK_GBS * 1e9), 4)},
             "signal_checksum": float(np.sum(all_sig[0][-1])),
@@ -515,8 +599,9 @@ def main():
         if world == 1 and args.side_configs and ngrid == N_GRID and E == 1 and not args.stub_env:
             for en in envs:  # (a context takes the resident path only when it has the device to itself)
                 en.ctx.close()
-            out["configs"] = {"config4_2048_w2": side_config(w, ds, dev, args.impl, 2048, 2.0, 6, traffic_tab),
-                              "config1_size_256": side_config(w, ds, dev, args.impl, 256, 2.0, 10, traffic_tab)}
+            out["configs"] = {f"config4_2048_w{int(pw)}": sweep_config(w, ds, dev, args.impl, 2048, pw, 500, traffic_tab)
+                              for pw in (1.0, 2.0, 4.0)}
+            out["configs"]["config1_size_256"] = side_config(w, ds, dev, args.impl, 256, 2.0, 10, traffic_tab)
         if world == 1 and args.side_configs and ngrid == N_GRID and E == 1 and not args.stub_env:
             out["rollout_config5"] = rollout_config5(w, dim, ds, dev, args.impl, args.pml_width)
         if world == 1 and args.batch_envs > 1 and E == 1 and not args.stub_env:

@@ -1,0 +1,141 @@
+"""Round-3 parity and behaviour tests through the C ABI: the resident launch that outlives the action (jobs), BASELINE
+config 5 in its single-GPU form, the headline configuration with the device-built source, the shared-GPU rule of the
+multi-rank launcher."""
+import gc
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+import waves_jl_amd as w
+import waves_oracle as wo
+from helpers import flat_design, oracle_integrate, rel_err
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+ENERGY_RTOL = 1e-5
+
+
+def _env(n, steps, actions, seed, **kw):
+    dim = w.TwoDim(15.0, n)
+    src = w.RandomPosGaussianSource(w.build_grid(dim), [[-10.0, -10.0]], [[-10.0, 10.0]], [0.3], [1.0], 1000.0,
+                                    rng=np.random.default_rng(seed + 2))
+    env = w.WaveEnv(dim, design_space=w.build_triple_ring_design_space(), source=src, integration_steps=steps, actions=actions,
+                    rng=np.random.default_rng(seed), return_fields=False, **kw)
+    pol = w.RandomDesignPolicy(env.action_space(), np.random.default_rng(seed + 1))
+    env.reset()
+    return env, pol
+
+
+def test_headline_config_with_the_device_built_source_vs_oracle():
+    """BASELINE config 2 exactly as bench.py / WaveEnv build it -- the source shape made ON THE DEVICE by
+    wv_set_gaussian_source (the env's RandomPosGaussianSource.reset), not uploaded from the oracle -- two consecutive env
+    actions through the resident launch, against the C oracle fed the device's own shape (as smoke() does at 128^2):
+    every field of the three frames bit for bit, traces to 1e-5."""
+    gc.collect()
+    env, pol = _env(700, 100, 2, 40)
+    dim = wo.TwoDim.from_size(15.0, 700)
+    G = np.array(env.ctx.source_shape())               # what k_gaussian wrote (<= 2 ulp from build_normal: tested elsewhere)
+    Gref = wo.build_normal(wo.build_grid(dim), np.asarray(env.source.mu, f32).reshape(1, 2), np.array([0.3], f32), np.array([1.0], f32))
+    assert np.abs(G - Gref).max() <= 3e-7 * np.abs(Gref).max()
+    state = np.zeros((12, 700, 700), f32)
+    while not env.is_terminated():
+        tspan, interp, _, _ = env(pol(env))
+        assert env.ctx.timing()["resident"] is True
+        (p0, r0, c0), (p1, r1, c1), ti, tf = interp.abi_args()
+        d0 = np.concatenate([p0, r0[:, None], c0[:, None]], 1)
+        d1 = np.concatenate([p1, r1[:, None], c1[:, None]], 1)
+        state, rsig, fr = oracle_integrate(dim, state, tspan, G=G, freq=1000.0, d0=d0, d1=d1, ti=ti, tf=tf, frame_steps=(80, 90, 100))
+        frames = env.ctx.get_frames()
+        for k in range(3):
+            assert np.array_equal(wo.to_abi(frames[:, :, :, k]), fr[k]), f"frame {k}"
+        assert rel_err(env.signal[:, :2], rsig[:, :2]) < ENERGY_RTOL
+        assert np.abs(env.signal[:, 2] - rsig[:, 2]).max() <= ENERGY_RTOL * rsig[:, 0].max()
+    env.ctx.close()
+
+
+def test_config5_rollout_single_gpu_form_batched_equals_the_loop():
+    """BASELINE config 5 on one GPU: 20 actions x 100 integration steps at 700^2 with RandomDesignPolicy.  The rollout as ONE
+    device call (rollout_batched, wv_set_design_sequence), as the plain env(action) loop and as the two-in-flight loop give
+    the same traces, the same env.wave and the same bookkeeping, bit for bit."""
+    gc.collect()
+    res = {}
+    for mode in ("loop", "pipelined", "batched"):
+        env, pol = _env(700, 100, 20, 50)
+        if mode == "loop":
+            sigs = []
+            while not env.is_terminated():
+                env(pol(env))
+                sigs.append(env.signal)
+        elif mode == "pipelined":
+            sigs = w.rollout_pipelined(env, pol, 20)
+        else:
+            sigs = w.rollout_batched(env, pol, 20)
+        assert env.is_terminated() and len(sigs) == 20
+        res[mode] = (np.stack(sigs), env.ctx.get_frames(), env.time_step, env.design.stacked().r.copy(), float(sum(s.sum() for s in sigs)))
+        env.ctx.close()
+        gc.collect()
+    for mode in ("pipelined", "batched"):
+        for a, b in zip(res["loop"][:4], res[mode][:4]):
+            assert np.array_equal(a, b), mode
+    sig = res["loop"][0]
+    assert sig.shape == (20, 101, 3) and np.isfinite(sig).all() and sig[-1, -1, 0] > 0
+    for k in range(1, 20):   # row 1 of an action == last row of the previous one (src/env.jl:105-114)
+        assert np.array_equal(sig[k, 0], sig[k - 1, -1])
+
+
+def test_the_resident_launch_serves_consecutive_actions_and_leaves_when_asked():
+    """The jobs mechanism itself: consecutive env(action) calls are served by ONE launch (timing: launch_jobs), a call that
+    needs the stream (reset, get_state, observation) makes it leave first, a launch left alone leaves on its idle limit
+    and the next action simply starts another one -- results equal a context that launches per call (WAVES_AMD_PERSIST=0)."""
+    gc.collect()
+
+    def run(persist, pause):
+        os.environ["WAVES_AMD_PERSIST"] = "1" if persist else "0"
+        try:
+            env, pol = _env(300, 30, 8, 60)
+        finally:
+            del os.environ["WAVES_AMD_PERSIST"]
+        sigs = []
+        for k in range(6):
+            env(pol(env))
+            sigs.append(env.signal)
+            if pause and k == 2:
+                time.sleep(0.05)          # far beyond the idle limit (1 ms): the launch has left
+            if k == 3:
+                obs = env.state().wave    # needs the frames on the stream: the launch is told to leave
+        env.ctx.synchronize()
+        t = env.ctx.timing()
+        out = (np.stack(sigs), env.ctx.get_frames(), obs)
+        env.ctx.close()
+        gc.collect()
+        return out, t
+
+    ref, t0 = run(False, False)
+    got, t1 = run(True, False)
+    got2, t2 = run(True, True)
+    for a, b, c in zip(ref, got, got2):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert t0["launch_jobs"] == 1                 # one launch per call
+    assert t1["launch_jobs"] == 2 and t1["launch_ms"] > 0   # actions 5 and 6 (after the observation) shared the last launch
+    assert t2["launch_jobs"] == 2
+
+
+def test_shared_gpu_ranks_stay_off_the_resident_kernel():
+    """VERDICT r2 item 3 / ADVICE r2: two ranks rehearsed on ONE GPU (WAVES_AMD_ALLOW_SHARED_GPU=1, gloo) must both run the
+    single-step kernels -- two processes' resident grids on one device can each end up partly resident."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "WAVES_AMD_FUSED_RESIDENT")}
+    env["WAVES_AMD_ALLOW_SHARED_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-steps", "0",
+                        "--side-configs", "0", "--batch-envs", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["ranks_gathered"] == 2
+    assert d["roofline"]["kernel"] == "k_step_fused"

@@ -64,6 +64,45 @@ def run_env(n, steps, design, seed=0):
     return time.perf_counter() - t0, sol[:, :, :, -1], None
 
 
+def run_design_steps(n, steps, seed=0):
+    """`steps` integration steps of the config-2 workload (triple ring moving between two random designs, Gaussian source)
+    through the integrator alone -- no env bookkeeping, so that a bounded sample may be shorter than the 20 steps the env's
+    frame capture needs.  Same closures as WaveEnv's step builds (src/env.jl:95-102)."""
+    dim = wo.TwoDim.from_size(15.0, n)
+    grid = wo.build_grid(dim)
+    rng = np.random.default_rng(seed)
+    ds = wo.build_triple_ring_design_space()
+    a = wo.rand_design(ds, rng)
+    b = ds(a, wo.rand_design(wo.build_action_space(a, 0.25), rng))
+    ts = wo.build_tspan(0.0, 1e-5, steps)
+    interp = wo.DesignInterpolator(a, b, f32(0.0), ts[-1])
+    dyn = wo.AcousticDynamics.build(dim, wo.WATER, 2.0, 20000.0, f32)
+    it = wo.Integrator(wo.runge_kutta, dyn, f32(1e-5))
+    src = wo.Source(wo.build_normal(grid, np.array([[-10.0, 3.0]]), np.array([0.3]), np.array([1.0])), f32(1000.0))
+    C = lambda t: wo.speed(interp(t, f32), grid, dyn.c0)
+    F = lambda t: src(t, f32)
+    u = np.zeros((n, n, 12), f32)
+    t0 = time.perf_counter()
+    it(u, ts, [C, F], save={steps})
+    return time.perf_counter() - t0
+
+
+def bounded_sample(steps1=10, steps2=2):
+    """What bench.py reports as cpu_baseline.r1: a few steps of config 1 and config 2 on this host, one core."""
+    out = {}
+    stencil_dx, stencil_dy = wo.dx, wo.dy
+    try:
+        install_sparse_operators(wo.TwoDim.from_size(15.0, 256))
+        dt1, _, _ = run_env(256, steps1, False)
+        install_sparse_operators(wo.TwoDim.from_size(15.0, 700))
+        dt2 = run_design_steps(700, steps2)
+    finally:
+        wo.dx, wo.dy = stencil_dx, stencil_dy
+    out["config1_256"] = {"value": round(256 * 256 * steps1 / dt1 / 1e6, 4), "sample": f"{steps1} steps ({dt1:.1f} s)"}
+    out["config2_700"] = {"value": round(700 * 700 * steps2 / dt2 / 1e6, 4), "sample": f"{steps2} steps ({dt2:.1f} s)"}
+    return out
+
+
 def main():
     s1 = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     s2 = int(sys.argv[2]) if len(sys.argv) > 2 else 8

@@ -1339,6 +1339,7 @@ int wv_get_timing(wv_ctx *c, wv_timing *out)
 {
     CHECK_CTX(c);
     if (!out) return fail(c, WV_ERR_INVALID, "wv_get_timing: NULL");
+    fused_launch_stats(c->fused, &c->timing.launch_ms, &c->timing.launch_jobs);  // (a launch may have ended since the last call: wv_synchronize)
     *out = c->timing;
     return WV_OK;
 }
