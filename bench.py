@@ -315,12 +315,28 @@ def timed_rollout(env, policy, n_actions, in_flight=2):
         dev_ms += t["total_ms"]
         job_us.append(t["step_kernel_ms"] * 1e3 / max(t["step_kernel_launches"], 1))
 
+    prof = os.environ.get("WAVES_AMD_PYPROF")   # diagnostic: where the host's time per action goes (policy / begin / end)
+    tp = [0.0, 0.0, 0.0]
     for k in range(n_actions):
-        env.step_begin(policy(env))
+        if prof:
+            a = time.perf_counter()
+            act = policy(env)
+            b = time.perf_counter()
+            env.step_begin(act)
+            c_ = time.perf_counter()
+            tp[0] += b - a
+            tp[1] += c_ - b
+        else:
+            env.step_begin(policy(env))
         if k > 0 or in_flight < 2:
+            a = time.perf_counter()
             end()
+            tp[2] += time.perf_counter() - a
     if in_flight >= 2 and n_actions > 0:
         end()
+    if prof and n_actions:
+        print(f"[bench pyprof] per action (us): policy {tp[0] / n_actions * 1e6:.1f} | step_begin {tp[1] / n_actions * 1e6:.1f} | "
+              f"step_end (incl. waiting) {tp[2] / n_actions * 1e6:.1f}", file=sys.stderr)
     return sigs, kern_ms, launches, dev_ms
 
 

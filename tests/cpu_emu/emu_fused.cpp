@@ -35,6 +35,7 @@ static thread_local F2 g_lds_raw[lds_elems(8 * 6)];  // deliberately NOT cleared
 static thread_local bool g_probe_only = false;  // resident emulation: only poll the halo, do not run the step
 static int g_maxdrift = 0;
 static thread_local bool g_not_ready = false;  // set by a resident tile whose halo words have not all arrived
+static thread_local const int *g_cull = nullptr;  // resident emulation: the tile's cylinder list as the DEVICE culls it, or nullptr
 static int g_force_all = 0;  // 1: every tile runs the F_ALL instantiation (must give the same bits as the specialised ones)
 
 // Registers of one tile (type-erased: the register struct depends on the variant), kept from step to step in the
@@ -61,7 +62,7 @@ static void run_tile(const FusedParams &p, const StepIO &io, const TileDesc &t, 
     } else {  // the phase sequence of run_tile_resident
         if (mode == MODE_RESIDENT_FIRST) {
             for (int tid = 0; tid < NT; ++tid) {
-                fused_tile_init<AUX, FL, NW, RPT>(p, t, tid, cx[tid], regs[tid]);
+                fused_tile_init<AUX, FL, NW, RPT>(p, t, tid, cx[tid], regs[tid], g_cull);
                 fused_load_state<AUX, NW, RPT>(p, io.u, t, tid, regs[tid]);
             }
         } else {
@@ -198,6 +199,9 @@ struct Case {
     int src_mode = 1;  // 1: per-tile source flags computed; 0: src_flags = nullptr (assume non-zero everywhere)
     int resident = 0;  // 1: the protocol of k_steps_resident -- tiles keep their registers from step to step, re-read only
                        // their halo, and run in a random order constrained by nothing but the neighbour flags
+    int devcyl = 0;    // 1 (resident only): no cylinder table and no culled lists from the host -- the tiles evaluate the
+                       // DesignInterpolator themselves (design_cyl) and cull themselves (device_cull_keep), as FusedParams::dsg /
+                       // dev_cull make k_steps_resident do
 };
 
 static int run_case(const Case &cs)
@@ -330,6 +334,36 @@ static int run_case(const Case &cs)
     std::vector<double> es(3 * (size_t)nsteps, 0.0);
     std::vector<TileMem> mem(pl.tiles.size());
     const size_t nt = pl.tiles.size();
+    JobDesign dsg{};
+    std::vector<std::vector<int>> culls(nt);
+    if (cs.devcyl) {
+        if (M < 1 || M > FT_MAXCYL) { printf("%-28s devcyl needs 1 <= M <= %d\n", cs.name, FT_MAXCYL); return 1; }
+        dsg.M = M; dsg.ti = ti; dsg.tf = tf;
+        memcpy(dsg.d0, d0.data(), 4 * (size_t)M * sizeof(float));
+        memcpy(dsg.d1, d1.data(), 4 * (size_t)M * sizeof(float));
+        p.dsg = &dsg; p.tspan = tspan.data(); p.dev_cull = 1;
+        p.cull_t_lo = tspan[0]; p.cull_t_hi = tspan[nsteps - 1] + dt;
+        // the device's evaluation of the interpolator gives the host table's bits, its culling the host's lists
+        for (int s = 0; s < nsteps; ++s)
+            for (int q = 0; q < 3; ++q)
+                for (int m = 0; m < M; ++m) {
+                    const float tq = q == 0 ? tspan[s] : (q == 1 ? tspan[s] + hdt : tspan[s] + dt);
+                    const Cyl a = design_cyl(dsg, m, tq), b = table[(size_t)(3 * s + q) * M + m];
+                    if (memcmp(&a, &b, sizeof(Cyl)) != 0) { printf("%-28s design_cyl differs from the host table (step %d stage %d cyl %d)\n", cs.name, s, q, m); return 1; }
+                }
+        for (TileDesc &t : pl.tiles) {
+            std::vector<int> &c = culls[t.slot];
+            c.push_back(0);
+            for (int m = 0; m < M; ++m)
+                if (device_cull_keep(p, t, m)) c.push_back(m);
+            c[0] = (int)c.size() - 1;
+            bool same = c[0] == t.cyl_count;
+            for (int k = 0; same && k < t.cyl_count; ++k) same = c[1 + k] == idx[t.cyl_begin + k];
+            if (!same) { printf("%-28s device culling differs from the host's list (tile slot %d: %d vs %d cylinders)\n", cs.name, t.slot, c[0], t.cyl_count); return 1; }
+        }
+        p.cyl_tab = nullptr;   // neither the table nor the host's lists are there for the tiles to read
+        p.cyl_idx = nullptr;
+    }
     if (!cs.resident) {
         for (int s = 0; s < nsteps; ++s) {
             p.io = steps[s];
@@ -358,6 +392,7 @@ static int run_case(const Case &cs)
                 const int s = done[t.slot];
                 if (s >= nsteps) continue;
                 g_not_ready = false;
+                g_cull = cs.devcyl ? culls[t.slot].data() : nullptr;
                 double es_tile[3] = {0, 0, 0};
                 if (!run_dispatch(key, p, steps[s], t, es_tile, mem[t.slot], s == 0 ? MODE_RESIDENT_FIRST : MODE_RESIDENT_NEXT)) {
                     printf("unsupported NW/RF/RB/RP\n");
@@ -757,6 +792,8 @@ int main(int argc, char **argv)
         {"resident: tiny grid 9", 9, 5, 8, 4, 3, 2, 2.0f, 0.0f, 1, 1, 0, 0, 1, 1},
         {"resident: grid 57", 57, 6, 8, 4, 3, 2, 2.0f, 20000.0f, 2, 1, 0, 0, 1, 1},
         {"resident: F_ALL bodies", 150, 5, 8, 4, 3, 2, 2.0f, 20000.0f, 3, 1, 0, 1, 1, 1},
+        {"resident: device cylinders", 160, 7, 8, 4, 3, 2, 2.0f, 20000.0f, 6, 1, 0, 0, 1, 1, 1},
+        {"resident: device cyl, 2,2,2", 131, 6, 8, 2, 2, 2, 2.0f, 20000.0f, 19, 1, 0, 0, 1, 1, 1},
     };
     if (!quick) {
         cases.push_back({"config-2 like 700, 3 steps", 700, 3, 8, 4, 3, 2, 2.0f, 20000.0f, 19, 1, 0, 0});
@@ -765,6 +802,7 @@ int main(int argc, char **argv)
         cases.push_back({"600 cylinders (global-list path)", 200, 3, 8, 4, 3, 2, 2.0f, 20000.0f, 600, 1, 0, 0});
         cases.push_back({"resident: config-2 like 700", 700, 4, 8, 4, 3, 2, 2.0f, 20000.0f, 19, 1, 0, 0, 1, 1});
         cases.push_back({"resident: 600 cylinders", 200, 4, 8, 4, 3, 2, 2.0f, 20000.0f, 600, 1, 0, 0, 1, 1});
+        cases.push_back({"resident: device cyl, 700", 700, 3, 8, 4, 3, 2, 2.0f, 20000.0f, 19, 1, 0, 0, 1, 1, 1});
     }
     int fails = 0;
     for (const Case &c : cases) fails += run_case(c);

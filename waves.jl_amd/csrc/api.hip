@@ -93,6 +93,11 @@ struct wv_ctx {
         // what running the call once more needs (after the resident kernel gave it up)
         std::vector<FusedStep> fsteps;
         FusedCall fcall{};
+        bool dev_mode = false;                       // the call ran without host-built cylinder tables (FusedDevTables) ...
+        std::vector<float> in_tspan, in_d0, in_d1;   // ... these are its inputs
+        float in_ti = 0.0f, in_tf = 0.0f;
+        int in_M = 0, in_rows[2] = {-1, -1};
+        bool in_capture = false;
         const float *row0 = nullptr;
         int nblocks = 0;
         bool pending = false;
@@ -782,6 +787,7 @@ struct HostProf {
     std::mutex mu;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long calls = 0;
+    bool warmed = false;
     static std::chrono::steady_clock::time_point &clock()
     {
         static thread_local std::chrono::steady_clock::time_point t;
@@ -791,9 +797,11 @@ struct HostProf {
     {
         if (!on) return;
         std::lock_guard<std::mutex> g(mu);
-        if (++calls == 6) {  // the first calls allocate / load code: not representative
+        ++calls;
+        if (!warmed && calls == 6) {  // the first calls allocate / load code: not representative
             for (double &a : acc) a = 0.0;
             calls = 1;
+            warmed = true;
         }
         clock() = std::chrono::steady_clock::now();
     }
@@ -872,26 +880,31 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     int row_lo = 0, row_hi = 0;  // rows of the earliest / latest stage time (bounding boxes of the cylinder culling)
     float t_lo = INFINITY, t_hi = -INFINITY;
     bool t_ok = true;
-    for (int s = 0; s < nsteps; ++s) {
-        // (a sequence: every action brings its own tspan of sps + 1 entries and its own interpolator)
-        const int act = seq_n > 0 ? s / sps : 0;
-        const float t = seq_n > 0 ? tspan[(size_t)act * (sps + 1) + (s - act * sps)] : tspan[s];
-        const float tq[3] = {t, t + hdt, t + dt};
-        for (int k = 0; k < 3; ++k) {
-            q.h_sfac[3 * s + k] = c->has_source ? source_factor(tq[k], c->freq) : 0.0f;
-            if (M > 0 && seq_n > 0)
-                design_at(M, c->seq_d.data() + (size_t)act * M * 4, c->seq_d.data() + (size_t)(act + 1) * M * 4, c->seq_t[2 * (size_t)act],
-                          c->seq_t[2 * (size_t)act + 1], tq[k], q.h_cyl + (size_t)(3 * s + k) * M);
-            else if (M > 0)
-                design_at(c, tq[k], q.h_cyl + (size_t)(3 * s + k) * M);
-            t_ok = t_ok && isfinite(tq[k]);
-            if (tq[k] < t_lo) { t_lo = tq[k]; row_lo = 3 * s + k; }
-            if (tq[k] > t_hi) { t_hi = tq[k]; row_hi = 3 * s + k; }
+    // the source's time factors (a double-precision sin each) and the stage-time range; the cylinders only when asked for
+    auto build_tables = [&](bool with_cylinders) {
+        t_lo = INFINITY;
+        t_hi = -INFINITY;
+        t_ok = true;
+        for (int s = 0; s < nsteps; ++s) {
+            // (a sequence: every action brings its own tspan of sps + 1 entries and its own interpolator)
+            const int act = seq_n > 0 ? s / sps : 0;
+            const float t = seq_n > 0 ? tspan[(size_t)act * (sps + 1) + (s - act * sps)] : tspan[s];
+            const float tq[3] = {t, t + hdt, t + dt};
+            for (int k = 0; k < 3; ++k) {
+                q.h_sfac[3 * s + k] = c->has_source ? source_factor(tq[k], c->freq) : 0.0f;
+                if (with_cylinders && M > 0 && seq_n > 0)
+                    design_at(M, c->seq_d.data() + (size_t)act * M * 4, c->seq_d.data() + (size_t)(act + 1) * M * 4, c->seq_t[2 * (size_t)act],
+                              c->seq_t[2 * (size_t)act + 1], tq[k], q.h_cyl + (size_t)(3 * s + k) * M);
+                else if (with_cylinders && M > 0)
+                    design_at(c, tq[k], q.h_cyl + (size_t)(3 * s + k) * M);
+                t_ok = t_ok && isfinite(tq[k]);
+                if (tq[k] < t_lo) { t_lo = tq[k]; row_lo = 3 * s + k; }
+                if (tq[k] > t_hi) { t_hi = tq[k]; row_hi = 3 * s + k; }
+            }
         }
-    }
-    if (!t_ok) row_lo = row_hi = -1;  // (a NaN time: let the culling look at every row)
-    if (seq_n > 0) row_lo = row_hi = -1;  // (a sequence is not ONE monotone interpolation: every row)
-    g_hostprof.lap(0);
+        if (!t_ok) row_lo = row_hi = -1;  // (a NaN time: let the culling look at every row)
+        if (seq_n > 0) row_lo = row_hi = -1;  // (a sequence is not ONE monotone interpolation: every row)
+    };
     if (c->frames_exposed) {  // somebody holds the raw pointer of env.wave: assume it was written
         fused_state_changed(c->fused);
         c->elast_valid = false;
@@ -911,23 +924,48 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
             launch_there = false;
         }
     }
-    if (M > 0) HIPCHK(c, hipMemcpyAsync(q.d_cyl, q.h_cyl, ncyl * sizeof(Cyl), hipMemcpyHostToDevice, up));
-    HIPCHK(c, hipMemcpyAsync(q.d_sfac, q.h_sfac, nsf * sizeof(float), hipMemcpyHostToDevice, up));
-    g_hostprof.lap(1);
+    // A call that goes to a launch which is already there, with a design small enough for the tiles to evaluate and cull
+    // themselves (k_steps_resident, FusedParams::dsg / dev_cull), needs nothing from the host but the source's time factors:
+    // no cylinder table (91 KB per action at 700^2), no culling, no upload, no wait for a copy stream.
+    static const bool dev_tables_on = !(getenv("WAVES_AMD_DEV_TABLES") && atoi(getenv("WAVES_AMD_DEV_TABLES")) == 0);
+    bool dev_mode = dev_tables_on && launch_there && seq_n == 0 && M >= 1 && M <= kDevTablesMaxCyl && nsteps >= 2 && nsteps <= kDevTablesMaxSteps &&
+                    fused_dev_tables_ok(c->fused);
+    build_tables(!dev_mode);
+    if (dev_mode && !t_ok) {
+        dev_mode = false;
+        build_tables(true);
+    }
+    g_hostprof.lap(0);
+    // everything a call's kernels need from the host when the tiles do NOT help themselves
+    auto host_prepare = [&](bool there) -> int {
+        if (M > 0) HIPCHK(c, hipMemcpyAsync(q.d_cyl, q.h_cyl, ncyl * sizeof(Cyl), hipMemcpyHostToDevice, up));
+        HIPCHK(c, hipMemcpyAsync(q.d_sfac, q.h_sfac, nsf * sizeof(float), hipMemcpyHostToDevice, up));
+        g_hostprof.lap(1);
+        if (impl == WV_IMPL_FUSED) {
+            const int r2 = fused_prepare(c->fused, si, c->d_frames, frame(c, 2), other2(c), c->cur2 ^ 1, c->d_scratch[0], c->d_scratch[1],
+                                         capture != 0, c->has_source ? c->d_G : nullptr, q.d_cyl, M > 0 ? q.h_cyl : nullptr, M, 3 * nsteps, st,
+                                         up, row_lo, row_hi, there);
+            if (r2) return fail(c, r2 == 2 ? WV_ERR_INVALID : WV_ERR_HIP, "fused_prepare failed");
+            if (fused_generation(c->fused) != c->elast_generation) c->elast_valid = false;
+            c->elast_generation = fused_generation(c->fused);
+        } else if (up != st) {
+            HIPCHK(c, hipEventRecord(c->up_ev, up));
+            HIPCHK(c, hipStreamWaitEvent(st, c->up_ev, 0));
+        }
+        return WV_OK;
+    };
     if (impl == WV_IMPL_FUSED) {
         // (WAVES_AMD_FORCE_RESIDENT=1: experiments with several co-resident resident kernels -- the caller answers for
         // the sum of their tiles fitting the device's block slots)
         fused_allow_resident(c->fused, force_res || g_live_ctx[c->cfg.device & 63] <= 1);
         fused_allow_persist(c->fused, may_stay);
-        rc = fused_prepare(c->fused, si, c->d_frames, frame(c, 2), other2(c), c->cur2 ^ 1, c->d_scratch[0], c->d_scratch[1], capture != 0,
-                           c->has_source ? c->d_G : nullptr, q.d_cyl, M > 0 ? q.h_cyl : nullptr, M, 3 * nsteps, st, up, row_lo,
-                           row_hi, launch_there);
-        if (rc) return fail(c, rc == 2 ? WV_ERR_INVALID : WV_ERR_HIP, "fused_prepare failed");
-        if (fused_generation(c->fused) != c->elast_generation) c->elast_valid = false;
-        c->elast_generation = fused_generation(c->fused);
-    } else if (up != st) {
-        HIPCHK(c, hipEventRecord(c->up_ev, up));
-        HIPCHK(c, hipStreamWaitEvent(st, c->up_ev, 0));
+    }
+    if (dev_mode) {
+        fused_prepare_light(c->fused, si);
+        g_hostprof.lap(1);
+    } else {
+        rc = host_prepare(launch_there);
+        if (rc) return rc;
     }
     g_hostprof.lap(2);
     const int nblocks = impl == WV_IMPL_STAGED ? staged_energy_blocks(c->grid) : fused_energy_blocks(c->fused);
@@ -1082,8 +1120,19 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
         // itself, straight into q.h_signal, and is timed by its own clock stamps); the single-step path puts its launches
         // between two events.
         const FusedEnergy ef{row0, q.d_epart, want_signal ? q.h_signal : nullptr, c->dOmega};
-        if (fused_run(c->fused, si, fcall, c->fsteps.data(), (int)c->fsteps.size(), st, up, ef, may_stay, q.kev[0], q.kev[1]) != 0)
-            return fail(c, WV_ERR_HIP, std::string("fused_run failed: ") + hipGetErrorString(hipGetLastError()));
+        int fr = -1;
+        if (dev_mode) {
+            const FusedDevTables dev{M, c->d0.data(), c->d1.data(), c->ti, c->tf, tspan, c->has_source ? q.h_sfac : nullptr, t_lo, t_hi};
+            fr = fused_run(c->fused, si, fcall, c->fsteps.data(), (int)c->fsteps.size(), st, up, ef, may_stay, q.kev[0], q.kev[1], &dev);
+            if (fr == 3) {  // the launch has left (idle limit) between the decision and the hand-over: the ordinary way
+                dev_mode = false;
+                build_tables(true);
+                rc = host_prepare(false);
+                if (rc) return rc;
+            }
+        }
+        if (!dev_mode) fr = fused_run(c->fused, si, fcall, c->fsteps.data(), (int)c->fsteps.size(), st, up, ef, may_stay, q.kev[0], q.kev[1]);
+        if (fr != 0) return fail(c, WV_ERR_HIP, std::string("fused_run failed: ") + hipGetErrorString(hipGetLastError()));
         q.resident = fused_last_resident(c->fused);
         q.bracketed = !q.resident;
         if (q.resident) q.prof_launches = 1;
@@ -1112,6 +1161,18 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     q.fcall = fcall;
     q.row0 = row0;
     q.nblocks = nblocks;
+    q.dev_mode = dev_mode;
+    if (dev_mode) {  // (a re-run on the single-step kernels has to build what this call did without)
+        q.in_tspan.assign(tspan, tspan + nsteps + 1);
+        q.in_d0 = c->d0;
+        q.in_d1 = c->d1;
+        q.in_ti = c->ti;
+        q.in_tf = c->tf;
+        q.in_M = M;
+        q.in_capture = capture != 0;
+        q.in_rows[0] = row_lo;
+        q.in_rows[1] = row_hi;
+    }
     // (nothing may be enqueued behind a resident launch that stays on the device: it would wait out the launch's idle limit)
     const bool stream_free = !(impl == WV_IMPL_FUSED && fused_persist_alive(c->fused));
     if (want_signal) {
@@ -1166,6 +1227,24 @@ static int rerun_after_give_up(wv_ctx *c, int si)
     for (int k = 0; k < 2; ++k) {
         wv_ctx::Slot &q = c->slot[order[k]];
         if (!q.pending || !q.resident) continue;
+        if (q.dev_mode) {  // the call was described to the tiles by its interpolator alone: the tables the single-step kernels read
+            const int M = q.in_M, n = q.nsteps;
+            const float dt = c->cfg.dt, hdt = 0.5f * dt;
+            for (int s = 0; s < n; ++s) {
+                const float tq[3] = {q.in_tspan[s], q.in_tspan[s] + hdt, q.in_tspan[s] + dt};
+                for (int k = 0; k < 3; ++k)
+                    design_at(M, q.in_d0.data(), q.in_d1.data(), q.in_ti, q.in_tf, tq[k], q.h_cyl + (size_t)(3 * s + k) * M);
+            }
+            HIPCHK(c, hipMemcpyAsync(q.d_cyl, q.h_cyl, 3 * (size_t)n * M * sizeof(Cyl), hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipMemcpyAsync(q.d_sfac, q.h_sfac, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
+            // (the buffers of this call are in q.fsteps; the plan only needs the tables, the culled lists and the tile order)
+            if (fused_prepare(c->fused, order[k], c->d_frames, const_cast<float *>(q.fsteps.front().u), q.fsteps.back().out, 0, c->d_scratch[0],
+                              c->d_scratch[1], q.in_capture, c->has_source ? c->d_G : nullptr, q.d_cyl, q.h_cyl, M, 3 * n, st, st, q.in_rows[0],
+                              q.in_rows[1], false) != 0)
+                return fail(c, WV_ERR_HIP, "fused_prepare failed while a given-up call was prepared for the single-step kernels");
+            q.fcall.d_sfac = c->has_source ? q.d_sfac : nullptr;
+            q.dev_mode = false;
+        }
         if (fused_rerun_steps(c->fused, order[k], q.fcall, q.fsteps.data(), (int)q.fsteps.size(), st, q.kev[0], q.kev[1]) != 0)
             return fail(c, WV_ERR_HIP, std::string("the single-step kernels failed after a resident give-up: ") + hipGetErrorString(hipGetLastError()));
         if (q.want_signal) launch_energy_final(q.row0, q.d_epart, q.nsteps + 1, q.nblocks, c->dOmega, q.h_signal, nullptr, nullptr, st);

@@ -58,6 +58,17 @@ void fused_scratch_dirty(FusedPlan *p);  // somebody else wrote into the scratch
 void fused_source_changed(FusedPlan *p);  // the source shape was replaced
 // one step, eagerly, as a single launch over all tiles (profiling mode brackets these with events)
 void fused_launch(FusedPlan *p, int slot, const FusedCall &call, int step, const FusedStep &st, hipStream_t s);
+constexpr int kDevTablesMaxCyl = 32;     // == FT_MAXCYL (fused_body.h)
+constexpr int kDevTablesMaxSteps = 256;  // == JOB_MAXSTEPS
+// The small per-call tables of a call whose tiles evaluate their cylinders themselves (host memory, copied by the call).
+struct FusedDevTables {
+    int M;                 // 1 .. FT_MAXCYL cylinders
+    const float *d0, *d1;  // [M][4] {px, py, r, c}: DesignInterpolator(initial, final, ti, tf)
+    float ti, tf;
+    const float *tspan;    // [nsteps + 1], nsteps <= JOB_MAXSTEPS
+    const float *sfac;     // [nsteps][3] or nullptr (NoSource)
+    float t_lo, t_hi;      // the earliest / latest stage time of the call
+};
 // Where the energy trace of a call goes when the resident kernel produces it (the tiles do k_energy_final's second pass
 // themselves): row0 = partial sums of the initial state [blocks][3], epart = [nsteps + 1][blocks][3] (row s = after step s),
 // signal = PINNED HOST memory [(nsteps + 1)][3] or nullptr (no trace wanted).
@@ -73,11 +84,18 @@ struct FusedEnergy {
 // launch may stay on the device after this call.  The events bracket the single-step launches (they are not used by the
 // resident path, whose durations come from the launch's own events and the kernel's clock stamps).  Returns 0 on success.
 int fused_run(FusedPlan *p, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s, hipStream_t up,
-              const FusedEnergy &ef, bool keep, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+              const FusedEnergy &ef, bool keep, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
+              const FusedDevTables *dev = nullptr);
 // Resident path only.  Returns 0 when the job was handed over, -1 when this call cannot take that path (more tiles than
 // the device holds at once, a single step, ...; the caller then launches step by step), 1 on a HIP error.
 int fused_try_resident(FusedPlan *p, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s,
-                       hipStream_t up, const FusedEnergy &ef, bool keep);
+                       hipStream_t up, const FusedEnergy &ef, bool keep, const FusedDevTables *dev = nullptr);
+// With `dev` (only for a call that is handed to a resident launch which is already there: fused_persist_alive, and
+// fused_dev_tables_ok) the tiles evaluate the DesignInterpolator and cull their cylinders themselves; the caller then has
+// built no cylinder table, uploaded nothing and called fused_prepare_light instead of fused_prepare.  Returns 3 when the
+// launch has left meanwhile: nothing has happened, the caller prepares the call the ordinary way.
+bool fused_dev_tables_ok(FusedPlan *p);
+void fused_prepare_light(FusedPlan *p, int slot);
 // Wait for the slot's resident call: 0 done (also when the slot has none), 2 the resident kernel gave the call up -- nothing
 // has been written over its initial condition; run it again with fused_rerun_steps after fused_gave_up --, 1 HIP error.
 int fused_job_wait(FusedPlan *p, int slot, hipStream_t s);

@@ -58,6 +58,40 @@ struct TileDesc {
     int pad;
 };
 
+// DesignInterpolator(initial, final, ti, tf) as the data it is made of (src/designs.jl:274-292): M <= FT_MAXCYL cylinders as
+// {px, py, r, c}.  With it (FusedParams::dsg) the tiles evaluate their cylinders at the stage times themselves -- design_cyl
+// below, the host's design_at (api.hip) operation for operation -- instead of reading them from a [nsteps][3][M] table the
+// host has built and uploaded for every call (91 KB per 100-step action at M = 19).
+constexpr int FT_MAXCYL = 32;    // cylinders of one tile staged in LDS (more: read from global memory)
+struct JobDesign {
+    int M;
+    float ti, tf;
+    int pad;
+    float d0[FT_MAXCYL * 4];
+    float d1[FT_MAXCYL * 4];
+};
+
+// DesignInterpolator call at one time for one cylinder: src/designs.jl:287-292 with the algebra of :47-53, per scalar
+// component  v_i + ((v_f + (-1f0*v_i)) * (1f0/Dt)) * (clamp(t, ti, tf) - ti),  then r .^ 2 (src/designs.jl:102).  The same
+// operations in the same order as the host's design_at (api.hip), fp32, no contraction, correctly rounded division: the
+// same bits.
+WV_HD Cyl design_cyl(const JobDesign &d, int m, float t)
+{
+    float dt = d.tf - d.ti;
+    dt = dt > 0.0f ? dt : 1.0f;
+    const float inv_dt = 1.0f / dt;
+    const float tc = t < d.ti ? d.ti : (t > d.tf ? d.tf : t);
+    const float tau = tc - d.ti;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float vi = d.d0[4 * m + k], vf = d.d1[4 * m + k];
+        const float dy = vf + (-1.0f * vi);
+        v[k] = vi + (dy * inv_dt) * tau;
+    }
+    return Cyl{v[0], v[1], v[2] * v[2], v[3]};
+}
+
 // What differs between the steps of one wv_integrate call.
 struct StepIO {
     const float *u;   // state at the start of the step (12 planes)
@@ -110,6 +144,11 @@ struct FusedParams {
     int pad2;
     struct JobCtl *ctl;        // the launch's control block in device memory (flag arrays of the barriers)
     struct JobBack *back;      // diagnostic (WAVES_AMD_JOBLOG): where the leader tile stamps the phases of the job, or nullptr
+    // cylinders evaluated by the tiles themselves (cyl_tab == nullptr then): the interpolator and the tabulated times
+    const JobDesign *dsg;
+    const float *tspan;        // [nsteps + 1]
+    int dev_cull;              // the tiles also find out themselves which cylinders can reach them (device_cull_keep; cyl_idx unused)
+    float cull_t_lo, cull_t_hi;  // the earliest / the latest stage time of the call
 };
 
 // ---- jobs: the resident launch that outlives the action ---------------------------------------------------------------
@@ -127,10 +166,19 @@ enum : int { JOB_RUN = 1, JOB_EXIT = 2 };
 constexpr int JOB_MAX_TILES = 2048;  // (grids of the resident kernel: at most the block slots of the device, 512 on MI355X)
 enum : unsigned { JOBS_RUNNING = 0, JOBS_EXIT_TOLD = 1, JOBS_EXIT_IDLE = 2, JOBS_EXIT_ABORT = 3, JOBS_EXIT_LAST = 4 };
 
+constexpr int JOB_MAXSTEPS = 256;  // steps of a call whose per-step tables travel inside the job description
+struct JobDesc {                 // everything a job reads that differs from call to call and is small
+    FusedParams p;
+    // the tables of a call whose tiles evaluate and cull their cylinders themselves (p.dsg / p.tspan / p.sfac_tab then point at
+    // the device copy of these): no table is built, uploaded or waited for on the host's path
+    JobDesign dsg;
+    float tspan[JOB_MAXSTEPS + 1];
+    float sfac[3 * JOB_MAXSTEPS];
+};
 struct JobMail {                 // pinned host memory; written by the host, read by the leader block
     unsigned bell;               // number of the newest job described (monotonic)
     unsigned pad[15];
-    FusedParams desc[2];         // desc[seq & 1] describes job `seq` once bell >= seq
+    JobDesc desc[2];             // desc[seq & 1] describes job `seq` once bell >= seq
 };
 struct JobBack {                 // pinned host memory; written by the device
     unsigned done;               // number of the newest job whose outputs (state, frames, trace rows) are complete
@@ -147,7 +195,7 @@ struct JobGo {
 struct JobCtl {                  // device memory
     JobGo go[2];                 // [seq & 1]
     unsigned pad[12];
-    FusedParams jobs[2];         // the leader's copies of JobMail::desc
+    JobDesc jobs[2];             // the leader's copies of JobMail::desc
     // followed by flag arrays of `ntiles` words each (job_flags): 0 = A "reached the end of the last step" (nobody has given
     // up: the final state may now replace the initial condition), 1 = B "all stores of the job have left"
 };
@@ -168,8 +216,6 @@ struct JobArgs {
 // LDS image of one tile, carved out of one raw buffer (the kernel instantiates field sets with different RY over the
 // same allocation): two buffers of two (RY + 2) x FT_LX arrays of (total, incident) pairs (one guard row above and
 // below), then the boundary side buffers and the staged cylinders.
-constexpr int FT_MAXCYL = 32;    // cylinders of one tile staged in LDS (more: read from global memory)
-
 struct FusedLds {
     F2 *W[2], *Vy[2];    // [stage parity]: stage S reads buffer (S-1)&1 and publishes stage S+1 into buffer S&1
     F2 *XL[2], *XR[2];   // [parity][row][3 cells][W, Vx]   raw values at gx = 0,1,2 / nx-3,nx-2,nx-1
@@ -356,8 +402,43 @@ WV_HD int wv_wave_of(int tid)
 #endif
 }
 // ---- phase 0a: what a tile keeps for all its steps -------------------------------------------------------------
+// Which cylinders can reach a tile's region at ANY stage time of the call: the device's version of plan_build_cyl
+// (fused_plan.h), formula for formula and in double like it, so that host and device arrive at the same lists.  The
+// interpolation is linear in a clamped time and rounded monotonically, so every component takes its extremes at the
+// earliest and the latest stage time.  Conservative (margins far above fp32 round-off): a cylinder that is dropped has
+// mask == false at every cell of the region, so dropping it is exact.
+WV_HD bool device_cull_keep(const FusedParams &p, const TileDesc &t, int m)
+{
+    const Cyl a = design_cyl(*p.dsg, m, p.cull_t_lo), b = design_cyl(*p.dsg, m, p.cull_t_hi);
+    const bool ok = a.px - a.px == 0.0f && a.py - a.py == 0.0f && a.r2 - a.r2 == 0.0f && b.px - b.px == 0.0f && b.py - b.py == 0.0f &&
+                    b.r2 - b.r2 == 0.0f;  // all finite
+    if (!ok) return true;
+    const double pxmin = a.px < b.px ? (double)a.px : (double)b.px, pxmax = a.px < b.px ? (double)b.px : (double)a.px;
+    const double pymin = a.py < b.py ? (double)a.py : (double)b.py, pymax = a.py < b.py ? (double)b.py : (double)a.py;
+    double r2 = 0.0;
+    r2 = (double)a.r2 > r2 ? (double)a.r2 : r2;
+    r2 = (double)b.r2 > r2 ? (double)b.r2 : r2;
+    const double rad = __builtin_sqrt(r2) * (1.0 + 1e-5);
+    const double mx = 1e-4 * (1.0 + __builtin_fabs(pxmin) + __builtin_fabs(pxmax) + rad);
+    const double my = 1e-4 * (1.0 + __builtin_fabs(pymin) + __builtin_fabs(pymax) + rad);
+    const double rr = rad + (mx > my ? mx : my);
+    const double bx0 = pxmin - rr, bx1 = pxmax + rr, by0 = pymin - rr, by1 = pymax + rr;
+    const int rx0 = t.x0 - FT_H > 0 ? t.x0 - FT_H : 0, rx1 = t.x0 + t.ox + FT_H - 1 < p.nx - 1 ? t.x0 + t.ox + FT_H - 1 : p.nx - 1;
+    const int ry0 = t.y0 - FT_H > 0 ? t.y0 - FT_H : 0, ry1 = t.y0 + t.oy + FT_H - 1 < p.ny - 1 ? t.y0 + t.oy + FT_H - 1 : p.ny - 1;
+    const double xa = p.x[rx0], xb = p.x[rx1], ya = p.y[ry0], yb = p.y[ry1];
+    if (bx1 < xa || bx0 > xb || by1 < ya || by0 > yb) return false;
+    const double cx0 = bx0 + rr, cx1 = bx1 - rr, cy0 = by0 + rr, cy1 = by1 - rr;  // box of the possible centres
+    double ddx = xa - cx1 > cx0 - xb ? xa - cx1 : cx0 - xb;
+    ddx = ddx > 0.0 ? ddx : 0.0;
+    double ddy = ya - cy1 > cy0 - yb ? ya - cy1 : cy0 - yb;
+    ddy = ddy > 0.0 ? ddy : 0.0;
+    return !(ddx * ddx + ddy * ddy > rr * rr);
+}
+
+// cull_lds: the tile's cylinder list as the device found it ([0] count, [1 ...] indices), or nullptr: the host's list
 template <int AUX, int FL, int NW, int RPT>
-WV_HD void fused_tile_init(const FusedParams &p, const TileDesc &t, int tid, TileCtx &cx, FusedRegs<AUX, RPT> &r)
+WV_HD void fused_tile_init(const FusedParams &p, const TileDesc &t, int tid, TileCtx &cx, FusedRegs<AUX, RPT> &r,
+                           const int *cull_lds = nullptr)
 {
     const int lane = tid & 63, w = wv_wave_of(tid);
     const int gx = t.x0 - FT_H + lane;
@@ -368,7 +449,8 @@ WV_HD void fused_tile_init(const FusedParams &p, const TileDesc &t, int tid, Til
     cx.cyl_lds = cx.has_cyl && t.cyl_count > 0 && t.cyl_count <= FT_MAXCYL;
     r.sx = (AUX == AUX_PX || AUX == AUX_ALL) ? p.sx[cgx] : 0.0f;
     r.xs = ((FL & F_CYL) && cx.has_cyl) ? p.x[cgx] : 0.0f;
-    r.cidx = ((FL & F_CYL) && cx.cyl_lds && tid < 3 * t.cyl_count) ? p.cyl_idx[t.cyl_begin + tid % t.cyl_count] : 0;
+    r.cidx = ((FL & F_CYL) && cx.cyl_lds && tid < 3 * t.cyl_count)
+                 ? (cull_lds ? cull_lds[1 + tid % t.cyl_count] : p.cyl_idx[t.cyl_begin + tid % t.cyl_count]) : 0;
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
         const int ly = w + NW * rr;
@@ -390,8 +472,15 @@ template <int AUX, int FL, int RPT>
 WV_HD Cyl fused_cyl_fetch(const FusedParams &p, int step, const TileDesc &t, int tid, const TileCtx &cx,
                           const FusedRegs<AUX, RPT> &r)
 {
-    if ((FL & F_CYL) && cx.cyl_lds && tid < 3 * t.cyl_count)  // block-uniform up to the thread test
+    if ((FL & F_CYL) && cx.cyl_lds && tid < 3 * t.cyl_count) {  // block-uniform up to the thread test
+        if (p.dsg) {  // (block-uniform) stage times t, t + 0.5f0*dt, t + dt of the tabulated time (src/dynamics.jl:10-13)
+            const int q = tid / t.cyl_count;
+            const float t0 = p.tspan[step];
+            const float tq = q == 0 ? t0 : (q == 1 ? t0 + p.hdt : t0 + p.dt);
+            return design_cyl(*p.dsg, r.cidx, tq);
+        }
         return p.cyl_tab[(size_t)(3 * step + tid / t.cyl_count) * p.M + r.cidx];
+    }
     return Cyl{0.0f, 0.0f, 0.0f, 0.0f};
 }
 template <int FL>
@@ -1183,14 +1272,24 @@ WV_HD int job_try_fetch(const JobArgs &a, unsigned seq, int lane)
 {
     const unsigned par = seq & 1u;
     if (!job_reached(job_ld_sys(&a.mail->bell), seq)) return 0;
-    // the description, dword by dword: host memory -> device memory (sizeof(FusedParams) / 4 <= a few loads per lane)
+    // the description, dword by dword: host memory -> device memory (the parameters, and the per-step tables only when the
+    // job carries them: ~90 resp. ~1 400 dwords, all loads of a lane in flight together)
     const unsigned *src = reinterpret_cast<const unsigned *>(&a.mail->desc[par]);
     unsigned *dst = reinterpret_cast<unsigned *>(&a.ctl->jobs[par]);
-    constexpr int NW4 = (int)(sizeof(FusedParams) / 4);
-    for (int k = lane; k < NW4; k += JOB_LANES) job_st_agent(dst + k, job_ld_sys(src + k));
+    constexpr int NP4 = (int)(sizeof(FusedParams) / 4), NW4 = (int)(sizeof(JobDesc) / 4);
+    for (int k = lane; k < NP4; k += JOB_LANES) job_st_agent(dst + k, job_ld_sys(src + k));
     job_drain();
-    const unsigned got = job_ld_agent(&a.ctl->jobs[par].seq);  // (a description that is not the one rung: treat as "leave")
-    const int cmd = (got == seq && job_ld_agent(reinterpret_cast<const unsigned *>(&a.ctl->jobs[par].cmd)) == (unsigned)JOB_RUN) ? JOB_RUN : JOB_EXIT;
+    const unsigned got = job_ld_agent(&a.ctl->jobs[par].p.seq);  // (a description that is not the one rung: treat as "leave")
+    const int cmd = (got == seq && job_ld_agent(reinterpret_cast<const unsigned *>(&a.ctl->jobs[par].p.cmd)) == (unsigned)JOB_RUN) ? JOB_RUN : JOB_EXIT;
+    if (cmd == JOB_RUN && job_ld_agent(reinterpret_cast<const unsigned *>(&a.ctl->jobs[par].p.dev_cull)) != 0u) {
+        // (of the per-step tables only the rows of this call's steps)
+        const int ns = (int)job_ld_agent(reinterpret_cast<const unsigned *>(&a.ctl->jobs[par].p.nsteps));
+        constexpr int T4 = (int)(offsetof(JobDesc, tspan) / 4), S4 = (int)(offsetof(JobDesc, sfac) / 4);
+        const int t_end = T4 + ns + 1 < S4 ? T4 + ns + 1 : S4, s_end = S4 + 3 * ns < NW4 ? S4 + 3 * ns : NW4;
+        for (int k = NP4 + lane; k < t_end; k += JOB_LANES) job_st_agent(dst + k, job_ld_sys(src + k));
+        for (int k = S4 + lane; k < s_end; k += JOB_LANES) job_st_agent(dst + k, job_ld_sys(src + k));
+        job_drain();
+    }
     if (lane == 0) {
         if (cmd != JOB_RUN) {
             job_st_sys(&a.back->exit_seq[a.launch], seq);

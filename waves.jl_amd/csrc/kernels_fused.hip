@@ -210,6 +210,7 @@ __device__ WV_TILE_CALL bool run_tile_resident(const FusedParams *p0_, lds_f2_pt
     F2 *raw = (F2 *)raw_;
     float(*red)[NW] = (float(*)[NW])(float *)red_;
     int *vote = (int *)vote_;
+    const int *cull = vote + 1;  // the tile's cylinder list as the kernel found it (FusedParams::dev_cull): [0] count, [1 ...] indices
     const FusedLds lds = lds_view(raw, NW * RPT, RYMAX);
     FusedRegs<AUX, RPT> r;
     TileCtx cx;
@@ -220,7 +221,9 @@ __device__ WV_TILE_CALL bool run_tile_resident(const FusedParams *p0_, lds_f2_pt
     if (AUX == AUX_NONE) __builtin_amdgcn_s_setprio(2);
 #endif
     // the tile descriptor once, in scalar registers: a scalar load chain at the top of every step costs 1.3 %
-    const TileDesc t = load_tile(*opaque(p0));
+    TileDesc t = load_tile(*opaque(p0));
+    const bool dev_cull = opaque(p0)->dev_cull != 0;
+    if (dev_cull) t.cyl_count = __builtin_amdgcn_readfirstlane(cull[0]);
 #ifndef WV_TID_SPILLED  // (the first version, kept for A/B)
     // The thread index of a step is put together from the wave's index (a scalar) and the lane number: threadIdx.x itself,
     // live around the step loop, was kept in scratch and reloaded -- with a full wait -- at the top of every step.
@@ -232,7 +235,7 @@ __device__ WV_TILE_CALL bool run_tile_resident(const FusedParams *p0_, lds_f2_pt
     {
         const FusedParams &p = *opaque(p0);
         const int tid = opaque((int)threadIdx.x);
-        fused_tile_init<AUX, FL, NW, RPT>(p, t, tid, cx, r);
+        fused_tile_init<AUX, FL, NW, RPT>(p, t, tid, cx, r, dev_cull ? cull : nullptr);
         fused_cyl_commit<FL>(t, tid, lds, cx, fused_cyl_fetch<AUX, FL, RPT>(p, 0, t, tid, cx, r));  // steps[s].step == s
         fused_load_state<AUX, NW, RPT>(p, opaque(p.steps)[0].u, t, tid, r);
         if (tid == 0) *vote = 0;  // (set by a wave that gives up; read after the first barrier of a step)
@@ -451,7 +454,8 @@ __global__ __launch_bounds__(NW * 64, 4) void k_steps_resident(JobArgs a_)
     constexpr int RYMAX = NW * RMAX;
     __shared__ F2 raw[lds_elems(RYMAX)];
     __shared__ float red[3][NW];
-    __shared__ int vote[1];  // a wave of the block gave up waiting for its halo
+    __shared__ int vote[2 + FT_MAXCYL];  // [0]: a wave of the block gave up waiting for its halo; [1], [2 ...]: the tile's cylinder
+                                         // list when the tiles cull themselves (FusedParams::dev_cull): count, indices
     __shared__ unsigned s_job[4];  // the job's command and number (kept here, not in registers, across the tile body); leader
                                    // block: number and command of a job it has fetched ahead (0: none)
     static_assert(sizeof(double) * 3 * 256 <= sizeof(F2) * lds_elems(RYMAX), "the energy rows are summed in the tile's LDS image");
@@ -485,13 +489,24 @@ __global__ __launch_bounds__(NW * 64, 4) void k_steps_resident(JobArgs a_)
         if (blockIdx.x == 0 && threadIdx.x == 0) {  // diagnostic
             const JobArgs &a = *opaque(a0);
             const unsigned sq = s_job[1];
-            if (a.ctl->jobs[sq & 1u].back) job_st_sys64(&a.back->phase[sq & 1u][0], job_clock());
+            if (a.ctl->jobs[sq & 1u].p.back) job_st_sys64(&a.back->phase[sq & 1u][0], job_clock());
         }
         bool ok = true;
         {
-            const FusedParams *pj = uniform_ptr(&opaque(a0)->ctl->jobs[__builtin_amdgcn_readfirstlane(s_job[1]) & 1u]);
+            const FusedParams *pj = uniform_ptr(&opaque(a0)->ctl->jobs[__builtin_amdgcn_readfirstlane(s_job[1]) & 1u].p);
             const FusedParams &p = *opaque(pj);
-            const TileDesc t = load_tile(p);
+            TileDesc t = load_tile(p);
+            if (p.dev_cull) {  // (block-uniform) which cylinders can reach this tile during the call: one lane per cylinder
+                if (threadIdx.x < 64) {
+                    const int m = (int)threadIdx.x;
+                    const bool keep = m < p.M && device_cull_keep(p, t, m);
+                    const unsigned long long mask = __ballot(keep);
+                    if (keep) vote[2 + __popcll(mask & ((1ull << m) - 1ull))] = m;  // ascending, like the host's lists
+                    if (m == 0) vote[1] = __popcll(mask);
+                }
+                __syncthreads();
+                t.cyl_count = __builtin_amdgcn_readfirstlane(vote[1]);
+            }
 #define RUN(A, F, R) ok = run_tile_resident<A, F, NW, R, RYMAX>(pj, (lds_f2_ptr)raw, (lds_f_ptr)&red[0][0], (lds_i_ptr)vote)
             const int fl = tile_flags(p, t);
             const int fe = fl & F_EDGE;
@@ -524,7 +539,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_steps_resident(JobArgs a_)
         // ---- the end of the job (everything re-read: nothing is carried in registers across the tile body)
         const JobArgs &a = *opaque(a0);
         const unsigned seq = __builtin_amdgcn_readfirstlane(s_job[1]);
-        const FusedParams &p = *opaque(uniform_ptr(&a.ctl->jobs[seq & 1u]));
+        const FusedParams &p = *opaque(uniform_ptr(&a.ctl->jobs[seq & 1u].p));
         const int b = (int)blockIdx.x;
         if (!ok) {  // abandoned (block-uniform): tell the host why the launch is gone
             if (threadIdx.x == 0) {
@@ -700,6 +715,7 @@ struct FusedPlan {
     JobMail *mail = nullptr;      // pinned host memory
     JobBack *back = nullptr;      // pinned host memory
     JobCtl *d_ctl = nullptr;
+    const TileDesc *launch_tiles = nullptr;  // the (device) tile table the newest job with a host-built table was given
     int ctl_tiles = 0;            // tiles the flag arrays behind d_ctl were sized for
     unsigned seq = 0;             // jobs described so far (job numbers start at 1)
     // Launches: at most two are known at a time -- the newest, and the one before it while it still runs (a launch that ends
@@ -885,6 +901,11 @@ int fused_energy_blocks(FusedPlan *p)
 }
 
 void fused_source_changed(FusedPlan *p) { p->src_dirty = true; }
+
+// May a call skip fused_prepare (no culling, no tile upload) and let the tiles cull themselves?  Only with coordinates the
+// bounding-box culling is valid for, and a tile table from an earlier call of this tiling.
+bool fused_dev_tables_ok(FusedPlan *p) { return p->tiles_valid && p->hp.monotonic && p->launch_tiles != nullptr; }
+void fused_prepare_light(FusedPlan *p, int slot) { p->cur = slot; }
 
 void fused_scratch_dirty(FusedPlan *p) { p->scratch_clean = false; }
 
@@ -1089,6 +1110,7 @@ static int resident_capacity(FusedPlan *pl)
     return device_slots(pl);
 }
 
+static_assert(kDevTablesMaxCyl == FT_MAXCYL && kDevTablesMaxSteps == JOB_MAXSTEPS, "fused.h and fused_body.h disagree");
 // ---- the action-outliving launch: host side ----------------------------------------------------------------------------
 static bool jobs_ensure(FusedPlan *pl, int ntiles)
 {
@@ -1168,7 +1190,7 @@ int fused_retire(FusedPlan *pl)
     if (!pl) return 0;
     if (fused_persist_alive(pl)) {
         pl->seq++;
-        FusedParams &d = pl->mail->desc[pl->seq & 1u];
+        FusedParams &d = pl->mail->desc[pl->seq & 1u].p;
         d = FusedParams{};
         d.seq = pl->seq;
         d.cmd = JOB_EXIT;
@@ -1242,7 +1264,7 @@ static int jobs_launch(FusedPlan *pl, unsigned first_seq, int ntiles, hipStream_
 // `up`: the stream the caller's uploads of this call went to (its tables must have arrived before the job may start);
 // `ef`: where the trace goes.  keep: the launch may stay on the device after the job (see FusedPlan::persist).
 int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s,
-                       hipStream_t up, const FusedEnergy &ef, bool keep)
+                       hipStream_t up, const FusedEnergy &ef, bool keep, const FusedDevTables *dev)
 {
     pl->cur = slot;
     const size_t nt = pl->hp.tiles.size();
@@ -1326,10 +1348,38 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
     p.ctl = pl->d_ctl;
     static const bool joblog_ = getenv("WAVES_AMD_JOBLOG") != nullptr;
     p.back = joblog_ ? pl->back : nullptr;
+    JobDesc &desc = pl->mail->desc[p.seq & 1u];
+    if (dev) {
+        // The tiles evaluate and cull their cylinders themselves and find the call's small tables in the job description:
+        // nothing was built, uploaded or has to be waited for.  The tile table is the one the launch's first job was given
+        // (the launch order is a matter of speed only; it stays as that job's culling shaped it).
+        if (!alive) return 3;  // (it has left since the caller looked: nothing has happened yet)
+        if (!pl->launch_tiles || dev->M < 1 || dev->M > FT_MAXCYL || nsteps > JOB_MAXSTEPS) return 1;  // (the caller checked)
+        JobDesc *dj = &pl->d_ctl->jobs[p.seq & 1u];  // (device address)
+        desc.dsg.M = dev->M;
+        desc.dsg.ti = dev->ti;
+        desc.dsg.tf = dev->tf;
+        memcpy(desc.dsg.d0, dev->d0, 4 * (size_t)dev->M * sizeof(float));
+        memcpy(desc.dsg.d1, dev->d1, 4 * (size_t)dev->M * sizeof(float));
+        memcpy(desc.tspan, dev->tspan, (size_t)(nsteps + 1) * sizeof(float));
+        if (dev->sfac) memcpy(desc.sfac, dev->sfac, 3 * (size_t)nsteps * sizeof(float));
+        p.dsg = &dj->dsg;
+        p.tspan = dj->tspan;
+        p.sfac_tab = call.G ? dj->sfac : nullptr;
+        p.cyl_tab = nullptr;
+        p.cyl_idx = nullptr;
+        p.M = dev->M;
+        p.dev_cull = 1;
+        p.cull_t_lo = dev->t_lo;
+        p.cull_t_hi = dev->t_hi;
+        p.tiles = pl->launch_tiles;
+    } else {
+        pl->launch_tiles = p.tiles;
+    }
     // Everything the job reads must be in device memory before the bell rings.  A launch that is already there cannot be
     // made to wait by the stream, so the host waits for the copy stream itself (the uploads are ~100 KB: they are long
     // done when the previous job ends, and in the two-in-flight rhythm this wait sits under that job).
-    if (alive) {
+    if (alive && (!dev || !same)) {
         if (hipEventRecord(pl->p_up, up) != hipSuccess) return 1;
         hipError_t q;
         while ((q = hipEventQuery(pl->p_up)) == hipErrorNotReady) {}
@@ -1345,8 +1395,9 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
     if (!alive && up != s) {  // the new launch waits in stream order
         if (hipEventRecord(pl->p_up, up) != hipSuccess || hipStreamWaitEvent(s, pl->p_up, 0) != hipSuccess) return 1;
     }
+    if (dev && !fused_persist_alive(pl)) return 3;  // (it left on its idle limit meanwhile: the caller takes the ordinary way)
     pl->seq++;
-    pl->mail->desc[pl->seq & 1u] = p;
+    desc.p = p;
     __atomic_store_n(&pl->mail->bell, pl->seq, __ATOMIC_RELEASE);
     if (!alive) {
         const int rc = jobs_launch(pl, pl->seq, (int)nt, s);
@@ -1463,9 +1514,10 @@ void fused_allow_persist(FusedPlan *p, bool allow) { p->allow_persist = allow; }
 static int fused_run_steps(FusedPlan *pl, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s, hipEvent_t ev_start);
 
 int fused_run(FusedPlan *pl, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s, hipStream_t up,
-              const FusedEnergy &ef, bool keep, hipEvent_t ev_start, hipEvent_t ev_stop)
+              const FusedEnergy &ef, bool keep, hipEvent_t ev_start, hipEvent_t ev_stop, const FusedDevTables *dev)
 {
-    const int rr = fused_try_resident(pl, slot, call, steps, nsteps, s, up, ef, keep);
+    const int rr = fused_try_resident(pl, slot, call, steps, nsteps, s, up, ef, keep, dev);
+    if (dev && rr != 0) return rr > 0 ? rr : 1;  // (a call without host tables has no other way to run)
     pl->cur = slot;
     pl->last_resident = rr == 0;
     if (rr >= 0) return rr;

@@ -105,6 +105,9 @@ class WaveEnv:
         self._pending.append((tspan, interp))
         self.design = next_design
         self.time_step += self.integration_steps
+        # The NEXT action's tspan (a Julia Float32 range evaluated in twice precision: ~35 us of numpy on its first use) is
+        # tabulated now, while the device is busy with this action; build_tspan memoises it.
+        build_tspan(self.time(), self.dt, self.integration_steps)
 
     def steps_begin(self, actions, keep_frames=False):
         """`for a in actions; env(a); end` (src/data.jl:22-27) enqueued as ONE device call: valid when the actions do not
