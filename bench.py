@@ -304,11 +304,16 @@ def timed_rollout(env, policy, n_actions, in_flight=2):
     in_flight = 1 is the plain `env(action)` loop."""
     sigs, kern_ms, launches, dev_ms = [], 0.0, 0, 0.0
     job_us = timed_rollout.job_us = []
+    fast = hasattr(env.ctx, "call_times_ms")   # resident calls: their durations are fetched once, behind the loop
+    if fast:
+        env.ctx.call_times_ms()                # (forget the warm-up's)
 
     def end():
         nonlocal kern_ms, launches, dev_ms
         env.step_end()
         sigs.append(env.signal)
+        if fast:
+            return
         t = env.ctx.timing()
         kern_ms += t["step_kernel_ms"]
         launches += t["step_kernel_launches"]
@@ -334,6 +339,16 @@ def timed_rollout(env, policy, n_actions, in_flight=2):
             tp[2] += time.perf_counter() - a
     if in_flight >= 2 and n_actions > 0:
         end()
+    if fast:
+        t = env.ctx.timing()
+        times = env.ctx.call_times_ms()
+        if t["resident"] and len(times) == n_actions:   # every action was a resident call: the kernel's own clock around each
+            job_us.extend(v * 1e3 for v in times)
+            kern_ms, launches, dev_ms = sum(times), n_actions, sum(times)
+        else:                                            # single-step path (or a mixture): the last call's event times stand for all
+            kern_ms = t["step_kernel_ms"] * n_actions
+            launches = t["step_kernel_launches"] * n_actions
+            dev_ms = t["total_ms"] * n_actions
     if prof and n_actions:
         print(f"[bench pyprof] per action (us): policy {tp[0] / n_actions * 1e6:.1f} | step_begin {tp[1] / n_actions * 1e6:.1f} | "
               f"step_end (incl. waiting) {tp[2] / n_actions * 1e6:.1f}", file=sys.stderr)
@@ -505,11 +520,17 @@ def main():
                 dev_ms += t_["total_ms"]
                 kern_ms += t_["step_kernel_ms"]
                 kern_launches += t_["step_kernel_launches"]
+    t_loop = time.perf_counter()
     all_sig = wd.gather_signals(np.stack(sigs))
+    t_gather = time.perf_counter()
     for en in envs:          # (the library's own sync point: a resident launch that is waiting for further actions leaves now,
         en.ctx.synchronize()  # instead of being waited out by the device-wide synchronisation below)
+    t_sync = time.perf_counter()
     sync_device()
     wd.barrier()
+    if os.environ.get("WAVES_AMD_PYPROF") and rank == 0:
+        print(f"[bench pyprof] timed region (ms): loop {1e3 * (t_loop - t0):.3f} | gather {1e3 * (t_gather - t_loop):.3f} | ctx.synchronize "
+              f"{1e3 * (t_sync - t_gather):.3f} | device sync + barrier {1e3 * (time.perf_counter() - t_sync):.3f}", file=sys.stderr)
     assert len(all_sig) == world
     elapsed = wd.max_over_ranks(time.perf_counter() - t0)
 

@@ -214,6 +214,10 @@ int wv_integrate_end_view(wv_ctx *ctx, float *signal, const float **u_tot, const
 /* measurement and plumbing */
 int wv_set_profiling(wv_ctx *ctx, int on); /* bracket every step kernel with HIP events (slower; for roofline) */
 int wv_get_timing(wv_ctx *ctx, wv_timing *out);
+/* Durations (ms, the resident kernel's own clock: wv_timing.step_kernel_ms) of the resident calls ended since the previous
+ * query, oldest first, at most `cap` (the newest ones); *n = how many were written.  Lets a benchmark loop collect per-call
+ * times without a wv_get_timing call inside the timed region. */
+int wv_get_call_times(wv_ctx *ctx, double *ms, int cap, int *n);
 int wv_set_stream(wv_ctx *ctx, void *hip_stream); /* run on a caller-owned hipStream_t (NULL: back to the ctx's own) */
 int wv_synchronize(wv_ctx *ctx);
 /* raw device pointer of env.wave (12*nx*ny*3 floats) for zero-copy interop (RCCL, torch); valid until wv_destroy.

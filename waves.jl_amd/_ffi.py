@@ -111,6 +111,7 @@ def lib():
     _sig(L, "wv_set_trajectory_stride", [ctx, C.c_int])
     _sig(L, "wv_set_profiling", [ctx, C.c_int])
     _sig(L, "wv_get_timing", [ctx, C.POINTER(wv_timing)])
+    _sig(L, "wv_get_call_times", [ctx, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)])
     _sig(L, "wv_set_stream", [ctx, _vp])
     _sig(L, "wv_synchronize", [ctx])
     _sig(L, "wv_device_frames", [ctx, C.POINTER(_vp), C.POINTER(C.c_size_t)])
@@ -141,6 +142,24 @@ def fortran(a, shape=None) -> np.ndarray:
     if shape is not None and tuple(a.shape) != tuple(shape):
         raise ValueError(f"expected shape {tuple(shape)}, got {tuple(a.shape)}")
     return a
+
+
+class _DesignAbi:
+    """One stacked design in the form wv_set_design takes: pos (M, 2) column-major, r (M,), c (M,), with their pointers.
+    Designs are immutable values and every design is handed over twice (as `final`, then as `initial`): built once."""
+    __slots__ = ("pos", "r", "c", "ptrs", "M")
+
+    def __init__(self, pos, r, c):
+        self.pos = fortran(np.asarray(pos, np.float32).reshape(-1, 2))
+        self.r = np.ascontiguousarray(r, np.float32).reshape(-1)
+        self.c = np.ascontiguousarray(c, np.float32).reshape(-1)
+        self.M = len(self.r)
+        assert self.pos.shape[0] == self.M and len(self.c) == self.M
+        self.ptrs = [fptr(self.pos), fptr(self.r), fptr(self.c)]
+
+
+def design_abi(pos, r, c) -> "_DesignAbi":
+    return _DesignAbi(pos, r, c)
 
 
 def device_count() -> int:
@@ -252,14 +271,14 @@ class Context:
         if initial is None:
             self._ck(self._L.wv_set_design(self._h, 0, None, None, None, None, None, None, float(ti), float(tf)))
             return
-        arrs = []
-        for pos, r, c in (initial, final):
-            arrs += [fortran(np.asarray(pos, np.float32).reshape(-1, 2)), np.ascontiguousarray(r, np.float32).reshape(-1),
-                     np.ascontiguousarray(c, np.float32).reshape(-1)]
-        M = len(arrs[1])
-        for a in arrs:
-            assert a.shape[0] == M
-        self._ck(self._L.wv_set_design(self._h, M, *[fptr(a) for a in arrs], float(ti), float(tf)))
+        arrs, ptrs = [], []
+        for d in (initial, final):
+            ab = getattr(d, "abi", None) or design_abi(*d)
+            arrs.append(ab)
+            ptrs += ab.ptrs
+        M = arrs[0].M
+        assert arrs[1].M == M
+        self._ck(self._L.wv_set_design(self._h, M, *ptrs, float(ti), float(tf)))
 
     def set_design_sequence(self, designs, ti_tf, steps_per_action):
         """The designs of n actions that the NEXT integrate call runs in one launch: designs = n + 1 tuples
@@ -389,6 +408,13 @@ class Context:
                 "step_kernel_launches": t.step_kernel_launches, "steps": t.steps,
                 "impl": {1: "staged", 2: "fused"}.get(t.impl, str(t.impl)), "resident": bool(t.resident),
                 "gave_up": bool(t.gave_up), "launch_ms": t.launch_ms, "launch_jobs": t.launch_jobs}
+
+    def call_times_ms(self, cap=4096):
+        """Durations (ms, the resident kernel's own clock) of the resident calls ended since the last query, oldest first."""
+        buf = (C.c_double * int(cap))()
+        n = C.c_int(0)
+        self._ck(self._L.wv_get_call_times(self._h, buf, int(cap), C.byref(n)))
+        return [buf[k] for k in range(n.value)]
 
     def set_stream(self, stream_handle):
         self._ck(self._L.wv_set_stream(self._h, _vp(stream_handle) if stream_handle else None))

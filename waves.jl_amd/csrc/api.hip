@@ -916,20 +916,22 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     const bool may_stay = impl == WV_IMPL_FUSED && !c->profiling && !shared && c->stream == c->own_stream && want_fields == 0 &&
                           !capture_all && !c->frames_exposed;
     bool launch_there = impl == WV_IMPL_FUSED && fused_persist_alive(c->fused);
+    const bool plan_needs_stream = c->fused && fused_needs_stream(c->fused, capture != 0, c->has_source ? c->d_G : nullptr, c->cur2 ^ 1);
     if (c->fused) {
-        const bool needs = !may_stay || (want_signal && !c->elast_valid) || (capture && nsteps == 2 * WV_FRAMESKIP) ||
-                           fused_needs_stream(c->fused, capture != 0, c->has_source ? c->d_G : nullptr, c->cur2 ^ 1);
+        const bool needs = !may_stay || (want_signal && !c->elast_valid) || (capture && nsteps == 2 * WV_FRAMESKIP) || plan_needs_stream;
         if (needs || impl != WV_IMPL_FUSED) {
             if (fused_retire(c->fused) != 0) return fail(c, WV_ERR_HIP, "wv_integrate_begin: the resident launch did not leave");
             launch_there = false;
         }
     }
-    // A call that goes to a launch which is already there, with a design small enough for the tiles to evaluate and cull
-    // themselves (k_steps_resident, FusedParams::dsg / dev_cull), needs nothing from the host but the source's time factors:
-    // no cylinder table (91 KB per action at 700^2), no culling, no upload, no wait for a copy stream.
+    // A call for the resident kernel with a design small enough for the tiles to evaluate and cull themselves
+    // (k_steps_resident, FusedParams::dsg / dev_cull) needs nothing from the host but the source's time factors: no cylinder
+    // table (91 KB per action at 700^2), no culling, no upload, no wait for a copy stream -- whether a launch is already
+    // there or a new one starts with this call (the first upload after an idle spell takes the copy engine ~0.4 ms).  The
+    // tile table is the one an earlier call of this tiling left on the device.
     static const bool dev_tables_on = !(getenv("WAVES_AMD_DEV_TABLES") && atoi(getenv("WAVES_AMD_DEV_TABLES")) == 0);
-    bool dev_mode = dev_tables_on && launch_there && seq_n == 0 && M >= 1 && M <= kDevTablesMaxCyl && nsteps >= 2 && nsteps <= kDevTablesMaxSteps &&
-                    fused_dev_tables_ok(c->fused);
+    bool dev_mode = dev_tables_on && impl == WV_IMPL_FUSED && !c->profiling && !plan_needs_stream && seq_n == 0 && M >= 1 &&
+                    M <= kDevTablesMaxCyl && nsteps >= 2 && nsteps <= kDevTablesMaxSteps && fused_dev_tables_ok(c->fused);
     build_tables(!dev_mode);
     if (dev_mode && !t_ok) {
         dev_mode = false;
@@ -1124,7 +1126,7 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
         if (dev_mode) {
             const FusedDevTables dev{M, c->d0.data(), c->d1.data(), c->ti, c->tf, tspan, c->has_source ? q.h_sfac : nullptr, t_lo, t_hi};
             fr = fused_run(c->fused, si, fcall, c->fsteps.data(), (int)c->fsteps.size(), st, up, ef, may_stay, q.kev[0], q.kev[1], &dev);
-            if (fr == 3) {  // the launch has left (idle limit) between the decision and the hand-over: the ordinary way
+            if (fr == 3) {  // not a call for the resident kernel after all (more tiles than the device holds, shared device, ...)
                 dev_mode = false;
                 build_tables(true);
                 rc = host_prepare(false);
@@ -1420,6 +1422,14 @@ int wv_get_timing(wv_ctx *c, wv_timing *out)
     if (!out) return fail(c, WV_ERR_INVALID, "wv_get_timing: NULL");
     fused_launch_stats(c->fused, &c->timing.launch_ms, &c->timing.launch_jobs);  // (a launch may have ended since the last call: wv_synchronize)
     *out = c->timing;
+    return WV_OK;
+}
+
+int wv_get_call_times(wv_ctx *c, double *ms, int cap, int *n)
+{
+    if (!c) return fail(nullptr, WV_ERR_INVALID, "ctx is NULL");
+    if (!n || (cap > 0 && !ms) || cap < 0) return fail(c, WV_ERR_INVALID, "wv_get_call_times: bad arguments");
+    *n = fused_job_times(c->fused, ms, cap);
     return WV_OK;
 }
 

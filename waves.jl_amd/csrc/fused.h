@@ -110,6 +110,7 @@ int fused_retire(FusedPlan *p);
 bool fused_needs_stream(FusedPlan *p, bool capture, const float *G, int out2_idx);
 void fused_allow_persist(FusedPlan *p, bool allow);  // per call: false ends the launch with the call
 double fused_last_job_ms(const FusedPlan *p);        // in-kernel duration of the resident call waited for last
+int fused_job_times(FusedPlan *p, double *ms, int cap);  // ... of the (last `cap`) resident calls since the previous query; clears
 void fused_launch_stats(const FusedPlan *p, double *ms, int *jobs);  // HIP-event duration and jobs of the launch that ended last
 // device word the resident kernel sets when it gives up / pinned host word of this slot the caller has it copied to
 const int *fused_abort_src(const FusedPlan *p);

@@ -575,13 +575,16 @@ __global__ __launch_bounds__(NW * 64, 4) void k_steps_resident(JobArgs a_)
             return;
         }
         if (p.back && b == 0 && threadIdx.x == 0) job_st_sys64(&p.back->phase[seq & 1u][5], job_clock());  // diagnostic
-        // the energy trace: block b sums the rows b, b + ntiles, ... straight into pinned host memory
+        // the energy trace: the blocks sum the rows straight into pinned host memory -- counted from the END of the launch order
+        // (block ntiles - 1 takes rows 0, ntiles, ...): the last positions hold the lightest tiles (plan_pair_order), which reach
+        // this point first and are not the ones their neighbours wait for at the next call's first exchange
         const int nrows = p.ef_signal ? p.nsteps + 1 : 0;
-        for (int row = b; row < nrows; row += p.ntiles) job_energy_row(p, row, reinterpret_cast<double *>(raw));
-        if (b < nrows) {  // my rows are in host memory (the host looks at these words, nobody on the device waits for them)
+        const int rb = p.ntiles - 1 - b;
+        for (int row = rb; row < nrows; row += p.ntiles) job_energy_row(p, row, reinterpret_cast<double *>(raw));
+        if (rb < nrows) {  // my rows are in host memory (the host looks at these words, nobody on the device waits for them)
             job_drain();
             __syncthreads();
-            if (threadIdx.x == 0) job_st_sys(&a.back->rowdone[b], seq);
+            if (threadIdx.x == 0) job_st_sys(&a.back->rowdone[rb], seq);
         }
         // the leader reports: state, frames and trajectories of the job are complete (barrier B)
         if (b == 0 && threadIdx.x == 0) {
@@ -890,6 +893,7 @@ static bool ensure_tiles(FusedPlan *p, bool aux_zero)
     p->src_dirty = true;
     p->tiles_valid = true;
     p->tiles_aux_zero = aux_zero;
+    p->launch_tiles = nullptr;  // (a table of the previous tiling)
     p->generation++;
     return true;
 }
@@ -1268,7 +1272,7 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
 {
     pl->cur = slot;
     const size_t nt = pl->hp.tiles.size();
-    if (nsteps < 2 || (int)nt > resident_capacity(pl) || (int)nt > JOB_MAX_TILES) return -1;
+    if (nsteps < 2 || (int)nt > resident_capacity(pl) || (int)nt > JOB_MAX_TILES) return dev ? 3 : -1;
     bool alive = fused_persist_alive(pl);
     // (a new tiling: new grid; no copy stream: the uploads would queue behind the launch they are meant for)
     if (alive && ((int)nt != pl->L[pl->cur_l].ntiles || s != pl->L[pl->cur_l].stream || up == s)) {
@@ -1284,7 +1288,7 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
     if (!jobs_ensure(pl, (int)nt)) {
         (void)hipGetLastError();
         pl->resident_capacity = 0;
-        return -1;
+        return dev ? 3 : -1;
     }
     // exchange buffer: zeroed once (tag 0 is never expected); tags only grow, so words of earlier calls -- or of an
     // earlier tile decomposition -- can never be mistaken for the ones a step waits for
@@ -1308,7 +1312,7 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
     for (int i = 0; i < nsteps; ++i) {
         tab[i] = StepIO{steps[i].u, (steps[i].keep || i + 1 == nsteps) ? steps[i].out : nullptr, steps[i].epart,
                         steps[i].traj_tot, steps[i].traj_inc, i, 0};
-        if (i > 0 && steps[i].u != steps[i - 1].out) return -1;
+        if (i > 0 && steps[i].u != steps[i - 1].out) return dev ? 3 : -1;
     }
     const bool same = tab.size() == pl->h_steps[slot].size() &&
                       memcmp(tab.data(), pl->h_steps[slot].data(), tab.size() * sizeof(StepIO)) == 0;
@@ -1353,7 +1357,6 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
         // The tiles evaluate and cull their cylinders themselves and find the call's small tables in the job description:
         // nothing was built, uploaded or has to be waited for.  The tile table is the one the launch's first job was given
         // (the launch order is a matter of speed only; it stays as that job's culling shaped it).
-        if (!alive) return 3;  // (it has left since the caller looked: nothing has happened yet)
         if (!pl->launch_tiles || dev->M < 1 || dev->M > FT_MAXCYL || nsteps > JOB_MAXSTEPS) return 1;  // (the caller checked)
         JobDesc *dj = &pl->d_ctl->jobs[p.seq & 1u];  // (device address)
         desc.dsg.M = dev->M;
@@ -1395,7 +1398,6 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
     if (!alive && up != s) {  // the new launch waits in stream order
         if (hipEventRecord(pl->p_up, up) != hipSuccess || hipStreamWaitEvent(s, pl->p_up, 0) != hipSuccess) return 1;
     }
-    if (dev && !fused_persist_alive(pl)) return 3;  // (it left on its idle limit meanwhile: the caller takes the ordinary way)
     pl->seq++;
     desc.p = p;
     __atomic_store_n(&pl->mail->bell, pl->seq, __ATOMIC_RELEASE);
@@ -1504,6 +1506,13 @@ const int *fused_abort_src(const FusedPlan *p) { return p->d_abort; }
 int *fused_abort_dst(FusedPlan *p, int slot) { return p->h_abort + slot; }
 
 double fused_last_job_ms(const FusedPlan *p) { return p->last_job_ms; }
+int fused_job_times(FusedPlan *p, double *ms, int cap)
+{
+    const int n = (int)std::min<size_t>(p->job_ms.size(), (size_t)std::max(cap, 0));
+    for (int k = 0; k < n; ++k) ms[k] = p->job_ms[p->job_ms.size() - (size_t)n + (size_t)k];
+    p->job_ms.clear();
+    return n;
+}
 void fused_launch_stats(const FusedPlan *p, double *ms, int *jobs)
 {
     *ms = p->last_launch_ms;

@@ -285,7 +285,23 @@ class DesignInterpolator:
         a, b = self.initial.stacked(), self.final.stacked()
         if a is None:
             return None, None, self.ti, self.tf
-        return (a.pos, a.r, a.c), (b.pos, b.r, b.c), self.ti, self.tf
+        return _abi_of(a), _abi_of(b), self.ti, self.tf
+
+
+class _AbiTuple(tuple):
+    """(pos, r, c) of a stacked design, as before, carrying the buffers Context.set_design hands to the library (built once
+    per design object: designs are immutable values and each is passed twice, as `final` and then as `initial`)."""
+    abi = None
+
+
+def _abi_of(cyl):
+    t = getattr(cyl, "_abi_tuple", None)
+    if t is None:
+        from . import _ffi
+        t = _AbiTuple((cyl.pos, cyl.r, cyl.c))
+        t.abi = _ffi.design_abi(cyl.pos, cyl.r, cyl.c)
+        cyl._abi_tuple = t
+    return t
 
 
 def hexagon_ring(r) -> np.ndarray:
