@@ -615,9 +615,12 @@ def main():
                                     if E == 1 else "4 envs at a time on their HIP streams",
                        "device_ms_per_step": round(dev_ms / args.steps, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": "profiles/traffic.json: rocprofv3 PMC bytes per launch of this kernel, collected "
-                                           "by tools/collect_profiles.sh in a separate run (replayed here, not measured live)"
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": (traffic * (launch_info["actions_served"] if resident and launch_info and launch_info["launches_in_timed_region"] == 1 else 1)
+                                     if traffic is not None else None),
+                         "traffic_source": "profiles/traffic.json: rocprofv3 PMC bytes of this kernel (resident: per action, times the "
+                                           "actions the launch served), collected by tools/collect_profiles.sh in a separate run "
+                                           "(replayed here, not measured live)"
                                            if traffic is not None else None,
                          "kernel": kname,
                          "avg_kernel_us": round(avg_ms * 1e3, 3), "event_bracketed_kernel_us": round(bracketed_us, 3),
@@ -628,7 +631,9 @@ def main():
                          "job_us": ({"min": round(job_us[0], 2), "median": round(job_us[len(job_us) // 2], 2), "max": round(job_us[-1], 2),
                                      "n": len(job_us), "what": "per action, the kernel's own 100 MHz clock: job seen -> state, frames, trace complete"}
                                     if job_us and resident else None),
-                         "algorithmic_bytes_per_launch": alg_bytes, "steps_per_launch": STEPS_PER_ACTION if resident else 1,
+                         "algorithmic_bytes_per_launch": alg_bytes * (launch_info["actions_served"] if launch_info and launch_info["launches_in_timed_region"] == 1 else 1),
+                         "steps_per_launch": (STEPS_PER_ACTION * (launch_info["actions_served"] if launch_info and launch_info["launches_in_timed_region"] == 1 else 1)) if resident else 1,
+                         "algorithmic_bytes_per_action": alg_bytes if resident else None,
                          "whole_job_frac": round(B_ALG * value * 1e6 / world / (HBM_PEAK_GBS * 1e9), 4)},
             "signal_checksum": float(np.sum(all_sig[0][-1])),
         }

@@ -10,6 +10,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <mutex>
 #include <vector>
 
 #include <hip/hip_ext.h>
@@ -658,6 +660,19 @@ __global__ __launch_bounds__(256) void k_src_flags(const TileDesc *__restrict__ 
 
 }  // namespace
 
+struct FusedPlan;
+// Plans that may have a launch waiting on the device.  A process that ends without destroying its contexts must not pull the
+// mailbox (pinned host memory the leader block polls) from under a running kernel: at exit every launch that stays is told to
+// leave -- with plain stores, no HIP call (the runtime may already be shutting down) -- and given a moment to say that it has.
+namespace {
+struct LiveLaunches {
+    std::mutex mu;
+    std::vector<FusedPlan *> plans;
+    ~LiveLaunches();
+};
+LiveLaunches g_live;
+}  // namespace
+
 struct FusedPlan {
     Grid g{};
     int NW = 8, RF = 4, RB = 3, RP = 2;  // rows per thread: AUX_NONE / AUX_PX, AUX_PY / AUX_ALL tiles
@@ -697,6 +712,7 @@ struct FusedPlan {
     const char *stamps_path = nullptr;
     // k_steps_resident (all steps of a call in one cooperative launch)
     bool use_resident = true;     // WAVES_AMD_FUSED_RESIDENT=0 disables
+    bool granules_checked = false;  // granules_ok() has been asked on behalf of this plan
     bool allow_resident = true;   // set per call by the owner (false: other contexts share the device)
     int max_polls = WV_WAIT_POLLS;
     int resident_capacity = -1;   // blocks of k_steps_resident the device holds at once (-1: not asked yet)
@@ -783,12 +799,20 @@ FusedPlan *fused_create(const Grid &g, const float *x, const float *y, const flo
         return nullptr;
     }
     p->h_abort[0] = p->h_abort[1] = 0;
+    {
+        std::lock_guard<std::mutex> g(g_live.mu);
+        g_live.plans.push_back(p);
+    }
     return p;
 }
 
 void fused_destroy(FusedPlan *p)
 {
     if (!p) return;
+    {
+        std::lock_guard<std::mutex> g(g_live.mu);
+        g_live.plans.erase(std::remove(g_live.plans.begin(), g_live.plans.end(), p), g_live.plans.end());
+    }
     (void)fused_retire(p);
     if (getenv("WAVES_AMD_HOSTPROF") && p->n_jobs)
         fprintf(stderr, "[waves_amd hostprof] resident launches %ld, jobs %ld, of them handed to a launch that was waiting: %ld\n",
@@ -1107,6 +1131,47 @@ static int device_slots(FusedPlan *pl)
     return pl->resident_capacity;
 }
 
+// The one hardware property the resident kernel's halo exchange relies on beyond the ISA's promises -- a 16-byte-aligned
+// 16-byte agent-scope access is never observed torn (fused_body.h, fused_xch_*) -- is checked ONCE per process and device,
+// before the first resident launch (a short run of wv_selftest_granules' experiment, ~2 ms): on a device where a granule
+// is ever seen torn the resident kernel is not used at all.  WAVES_AMD_SELFTEST=0 skips the check.
+static bool granules_ok(hipStream_t s)
+{
+    static std::mutex mu;
+    static int verdict[64] = {0};  // 0 not asked, 1 fine, -1 torn (or the check itself failed)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> g(mu);
+    int &v = verdict[dev & 63];
+    if (v != 0) return v > 0;
+    if (getenv("WAVES_AMD_SELFTEST") && atoi(getenv("WAVES_AMD_SELFTEST")) == 0) {
+        v = 1;
+        return true;
+    }
+    const unsigned bytes = 8u << 20;
+    unsigned char *buf = nullptr;
+    unsigned long long *out = nullptr, h[2] = {0, 0};
+    hipError_t e = hipMalloc((void **)&buf, bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&out, sizeof(h));
+    if (e == hipSuccess) e = hipMemsetAsync(out, 0, sizeof(h), s);
+    const unsigned strides[2] = {16u, 64u};
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+        e = hipMemsetAsync(buf, 0, bytes, s);
+        if (e == hipSuccess) launch_selftest_granules(buf, bytes, 3000, 64, strides[k], out, s);
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h, out, sizeof(h), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (buf) (void)hipFree(buf);
+    if (out) (void)hipFree(out);
+    if (e != hipSuccess) (void)hipGetLastError();
+    v = (e == hipSuccess && h[0] > 0 && h[1] == 0) ? 1 : -1;
+    if (v < 0)
+        fprintf(stderr, "[waves_amd] 16-byte granule self-test: %llu of %llu granules torn (status %d): the resident step kernel is not used "
+                        "on this device\n", h[1], h[0], (int)e);
+    return v > 0;
+}
+
 // ... and 0 when the resident path is not available to this call
 static int resident_capacity(FusedPlan *pl)
 {
@@ -1115,7 +1180,28 @@ static int resident_capacity(FusedPlan *pl)
 }
 
 static_assert(kDevTablesMaxCyl == FT_MAXCYL && kDevTablesMaxSteps == JOB_MAXSTEPS, "fused.h and fused_body.h disagree");
+
+
 // ---- the action-outliving launch: host side ----------------------------------------------------------------------------
+LiveLaunches::~LiveLaunches()
+{
+    std::lock_guard<std::mutex> g(mu);
+    for (FusedPlan *pl : plans) {
+        if (!pl->mail || !pl->back) continue;
+        const int l = pl->cur_l;
+        if (!pl->L[l].alive || !pl->L[l].stays || __atomic_load_n(&pl->back->status[l], __ATOMIC_ACQUIRE) != JOBS_RUNNING) continue;
+        pl->seq++;
+        FusedParams &d = pl->mail->desc[pl->seq & 1u].p;
+        d = FusedParams{};
+        d.seq = pl->seq;
+        d.cmd = JOB_EXIT;
+        __atomic_store_n(&pl->mail->bell, pl->seq, __ATOMIC_RELEASE);
+        const auto t0 = std::chrono::steady_clock::now();
+        while (__atomic_load_n(&pl->back->status[l], __ATOMIC_ACQUIRE) == JOBS_RUNNING &&
+               std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(50)) {}
+    }
+}
+
 static bool jobs_ensure(FusedPlan *pl, int ntiles)
 {
     if (!pl->mail) {
@@ -1274,6 +1360,13 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
     const size_t nt = pl->hp.tiles.size();
     if (nsteps < 2 || (int)nt > resident_capacity(pl) || (int)nt > JOB_MAX_TILES) return dev ? 3 : -1;
     bool alive = fused_persist_alive(pl);
+    if (!alive && !pl->granules_checked) {  // (before this plan's first resident launch; the stream is free then)
+        pl->granules_checked = true;
+        if (!granules_ok(s)) {
+            pl->use_resident = false;
+            return dev ? 3 : -1;
+        }
+    }
     // (a new tiling: new grid; no copy stream: the uploads would queue behind the launch they are meant for)
     if (alive && ((int)nt != pl->L[pl->cur_l].ntiles || s != pl->L[pl->cur_l].stream || up == s)) {
         if (fused_retire(pl)) return 1;
