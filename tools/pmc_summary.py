@@ -57,11 +57,13 @@ for sub in ("pmc1", "pmc2", "pmc3"):
         per[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
     for c, d in per.items():
         if main_kernel == "k_steps_resident":
-            # the timed dispatch is the one with the most work: by SQ_WAVES all dispatches are equal, so take it by position --
-            # dispatches appear in launch order: [warm-up launch, TIMED launch, profiling-mode launches ...]
+            # the timed dispatch is the one that served the most actions.  Work counters scale with the actions served, so it is
+            # the dispatch with the largest value; counters that do not (SQ_WAVES: the grid) are the same for every dispatch.
             ids = sorted(d, key=lambda x: int(x))
-            big = ids[1] if len(ids) > 1 else ids[0]
-            out["counters"][c] = {"timed_dispatch": d[big], "per_action": d[big] / STEPS, "dispatches": len(ids)}
+            big = max(ids, key=lambda x: d[x])
+            scales = c not in ("SQ_WAVES",)
+            out["counters"][c] = {"timed_dispatch": d[big], "per_action": d[big] / STEPS if scales else d[big], "dispatches": len(ids),
+                                  "all_dispatches": [d[x] for x in ids]}
         else:
             out["counters"][c] = {"mean_per_launch": sum(d.values()) / max(1, len(d)), "launches": len(d)}
 out["kernel"] = main_kernel

