@@ -94,7 +94,7 @@ def cpu_baseline(n_steps: int):
     try:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import r1_baseline
-        r1 = r1_baseline.bounded_sample(10, 2)
+        r1 = r1_baseline.bounded_sample(40, 6)
         out["r1_reference_structure"] = {"unit": "Mcell-updates/s", "cores": 1, "kind": "port (numpy + scipy.sparse, tools/r1_baseline.py)",
                                          **r1}
     except Exception as e:  # (scipy missing on some box: say so instead of failing the bench line)
@@ -423,7 +423,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20, help="timed env actions (100 integration steps each)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--impl", default="auto", choices=["auto", "staged", "fused"])
-    ap.add_argument("--cpu-steps", type=int, default=40, help="integration steps of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=160, help="integration steps of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--grid", type=int, default=N_GRID, help="grid points per axis (700 = the metric's configuration)")
     ap.add_argument("--pml-width", type=float, default=2.0)
     ap.add_argument("--envs-per-gpu", type=int, default=1,

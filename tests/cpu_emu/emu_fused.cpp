@@ -339,8 +339,7 @@ static int run_case(const Case &cs)
     if (cs.devcyl) {
         if (M < 1 || M > FT_MAXCYL) { printf("%-28s devcyl needs 1 <= M <= %d\n", cs.name, FT_MAXCYL); return 1; }
         dsg.M = M; dsg.ti = ti; dsg.tf = tf;
-        memcpy(dsg.d0, d0.data(), 4 * (size_t)M * sizeof(float));
-        memcpy(dsg.d1, d1.data(), 4 * (size_t)M * sizeof(float));
+        design_slopes(dsg, d0.data(), d1.data());
         p.dsg = &dsg; p.tspan = tspan.data(); p.dev_cull = 1;
         p.cull_t_lo = tspan[0]; p.cull_t_hi = tspan[nsteps - 1] + dt;
         // the device's evaluation of the interpolator gives the host table's bits, its culling the host's lists
@@ -710,8 +709,7 @@ static int run_jobs(const char *name, int scenario)
             // interpolator and cull themselves, the tile table is the one of the launch's first job
             JobDesc *dj = &ctl->jobs[seq & 1u];
             desc.dsg.M = M; desc.dsg.ti = tspan[0]; desc.dsg.tf = tspan[nsteps];
-            memcpy(desc.dsg.d0, d0.data(), 4 * (size_t)M * sizeof(float));
-            memcpy(desc.dsg.d1, d1.data(), 4 * (size_t)M * sizeof(float));
+            design_slopes(desc.dsg, d0.data(), d1.data());
             memcpy(desc.tspan, tspan.data(), (size_t)(nsteps + 1) * sizeof(float));
             memcpy(desc.sfac, sfac[slot].data(), 3 * (size_t)nsteps * sizeof(float));
             p.dsg = &dj->dsg; p.tspan = dj->tspan; p.sfac_tab = dj->sfac;

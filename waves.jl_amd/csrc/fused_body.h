@@ -67,28 +67,34 @@ struct JobDesign {
     int M;
     float ti, tf;
     int pad;
-    float d0[FT_MAXCYL * 4];
-    float d1[FT_MAXCYL * 4];
+    float d0[FT_MAXCYL * 4];     // v_i
+    float slope[FT_MAXCYL * 4];  // (v_f + (-1f0*v_i)) * (1f0/Dt), formed by design_slopes (on the host, once per call)
 };
 
 // DesignInterpolator call at one time for one cylinder: src/designs.jl:287-292 with the algebra of :47-53, per scalar
 // component  v_i + ((v_f + (-1f0*v_i)) * (1f0/Dt)) * (clamp(t, ti, tf) - ti),  then r .^ 2 (src/designs.jl:102).  The same
 // operations in the same order as the host's design_at (api.hip), fp32, no contraction, correctly rounded division: the
 // same bits.
-WV_HD Cyl design_cyl(const JobDesign &d, int m, float t)
+// (the time-independent half of the formula, once per call and cylinder instead of once per step, stage and tile)
+WV_HD void design_slopes(JobDesign &d, const float *d0, const float *d1)
 {
     float dt = d.tf - d.ti;
     dt = dt > 0.0f ? dt : 1.0f;
     const float inv_dt = 1.0f / dt;
+    for (int k = 0; k < 4 * d.M; ++k) {
+        const float vi = d0[k], vf = d1[k];
+        const float dy = vf + (-1.0f * vi);
+        d.d0[k] = vi;
+        d.slope[k] = dy * inv_dt;
+    }
+}
+WV_HD Cyl design_cyl(const JobDesign &d, int m, float t)
+{
     const float tc = t < d.ti ? d.ti : (t > d.tf ? d.tf : t);
     const float tau = tc - d.ti;
     float v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float vi = d.d0[4 * m + k], vf = d.d1[4 * m + k];
-        const float dy = vf + (-1.0f * vi);
-        v[k] = vi + (dy * inv_dt) * tau;
-    }
+    for (int k = 0; k < 4; ++k) v[k] = d.d0[4 * m + k] + d.slope[4 * m + k] * tau;
     return Cyl{v[0], v[1], v[2] * v[2], v[3]};
 }
 

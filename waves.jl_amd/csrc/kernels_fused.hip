@@ -1457,8 +1457,7 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
         desc.dsg.M = dev->M;
         desc.dsg.ti = dev->ti;
         desc.dsg.tf = dev->tf;
-        memcpy(desc.dsg.d0, dev->d0, 4 * (size_t)dev->M * sizeof(float));
-        memcpy(desc.dsg.d1, dev->d1, 4 * (size_t)dev->M * sizeof(float));
+        design_slopes(desc.dsg, dev->d0, dev->d1);
         memcpy(desc.tspan, dev->tspan, (size_t)(nsteps + 1) * sizeof(float));
         if (dev->sfac) memcpy(desc.sfac, dev->sfac, 3 * (size_t)nsteps * sizeof(float));
         p.dsg = &dj->dsg;
