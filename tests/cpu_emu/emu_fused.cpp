@@ -79,6 +79,7 @@ static void run_tile(const FusedParams &p, const StepIO &io, const TileDesc &t, 
         }
         for (int tid = 0; tid < NT; ++tid) {
             fused_step_init<FL>(p, io.step, cx[tid]);
+            fused_cyl_times<FL>(p, io.step, cx[tid]);
             // (on the device the fetch of a step > 0 is issued before the halo poll of the previous step and committed
             // after it; the tile's LDS image is private to the tile, so the emulation can do both here)
             fused_cyl_commit<FL>(t, tid, lds, cx[tid], fused_cyl_fetch<AUX, FL, RPT>(p, io.step, t, tid, cx[tid], regs[tid]));

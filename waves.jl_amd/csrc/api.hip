@@ -930,7 +930,10 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     // there or a new one starts with this call (the first upload after an idle spell takes the copy engine ~0.4 ms).  The
     // tile table is the one an earlier call of this tiling left on the device.
     static const bool dev_tables_on = !(getenv("WAVES_AMD_DEV_TABLES") && atoi(getenv("WAVES_AMD_DEV_TABLES")) == 0);
-    bool dev_mode = dev_tables_on && impl == WV_IMPL_FUSED && !c->profiling && !plan_needs_stream && seq_n == 0 && M >= 1 &&
+    // Only for a call that is not begun under another one's device work: there the host's table building, culling and
+    // uploads are hidden anyway, and the tiles' own evaluation costs the small grids more than it saves (256^2: +5 % per call).
+    static const bool dev_tables_always = getenv("WAVES_AMD_DEV_TABLES") && atoi(getenv("WAVES_AMD_DEV_TABLES")) == 2;
+    bool dev_mode = dev_tables_on && (c->n_pending == 0 || dev_tables_always) && impl == WV_IMPL_FUSED && !c->profiling && !plan_needs_stream && seq_n == 0 && M >= 1 &&
                     M <= kDevTablesMaxCyl && nsteps >= 2 && nsteps <= kDevTablesMaxSteps && fused_dev_tables_ok(c->fused);
     build_tables(!dev_mode);
     if (dev_mode && !t_ok) {

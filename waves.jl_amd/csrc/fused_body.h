@@ -67,8 +67,8 @@ struct JobDesign {
     int M;
     float ti, tf;
     int pad;
-    float d0[FT_MAXCYL * 4];     // v_i
-    float slope[FT_MAXCYL * 4];  // (v_f + (-1f0*v_i)) * (1f0/Dt), formed by design_slopes (on the host, once per call)
+    alignas(16) float d0[FT_MAXCYL * 4];     // v_i
+    alignas(16) float slope[FT_MAXCYL * 4];  // (v_f + (-1f0*v_i)) * (1f0/Dt), formed by design_slopes (on the host, once per call)
 };
 
 // DesignInterpolator call at one time for one cylinder: src/designs.jl:287-292 with the algebra of :47-53, per scalar
@@ -88,15 +88,18 @@ WV_HD void design_slopes(JobDesign &d, const float *d0, const float *d1)
         d.slope[k] = dy * inv_dt;
     }
 }
-WV_HD Cyl design_cyl(const JobDesign &d, int m, float t)
+WV_HD float design_tau(const JobDesign &d, float t)
 {
     const float tc = t < d.ti ? d.ti : (t > d.tf ? d.tf : t);
-    const float tau = tc - d.ti;
-    float v[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = d.d0[4 * m + k] + d.slope[4 * m + k] * tau;
-    return Cyl{v[0], v[1], v[2] * v[2], v[3]};
+    return tc - d.ti;
 }
+WV_HD Cyl design_cyl_tau(const JobDesign &d, int m, float tau)
+{
+    const Cyl a = reinterpret_cast<const Cyl *>(d.d0)[m], k = reinterpret_cast<const Cyl *>(d.slope)[m];  // (one 16-byte load each)
+    const float r = a.r2 + k.r2 * tau;  // (third component of a design entry: the radius)
+    return Cyl{a.px + k.px * tau, a.py + k.py * tau, r * r, a.c + k.c * tau};
+}
+WV_HD Cyl design_cyl(const JobDesign &d, int m, float t) { return design_cyl_tau(d, m, design_tau(d, t)); }
 
 // What differs between the steps of one wv_integrate call.
 struct StepIO {
@@ -293,6 +296,9 @@ struct TileCtx {
     bool has_src;  // the source shape is non-zero somewhere in this tile's region
     bool has_cyl;  // at least one cylinder can reach this tile's region
     bool cyl_lds;  // ... and the culled list is staged in LDS
+    float tau[3];  // tiles that evaluate their cylinders themselves: clamp(t, ti, tf) - ti at the three stage times of the step
+                   // whose cylinders are fetched next (fused_cyl_times: formed early in the step before, from scalar loads
+                   // whose latency the step hides -- formed next to the fetch they delayed every halo poll by ~0.5 us)
 };
 
 WV_HD bool tile_has_src(const FusedParams &p, const TileDesc &t)
@@ -479,15 +485,24 @@ WV_HD Cyl fused_cyl_fetch(const FusedParams &p, int step, const TileDesc &t, int
                           const FusedRegs<AUX, RPT> &r)
 {
     if ((FL & F_CYL) && cx.cyl_lds && tid < 3 * t.cyl_count) {  // block-uniform up to the thread test
-        if (p.dsg) {  // (block-uniform) stage times t, t + 0.5f0*dt, t + dt of the tabulated time (src/dynamics.jl:10-13)
+        if (p.dsg) {  // (block-uniform) the tile evaluates the interpolator itself: cx.tau was prepared for this `step`
             const int q = tid / t.cyl_count;
-            const float t0 = p.tspan[step];
-            const float tq = q == 0 ? t0 : (q == 1 ? t0 + p.hdt : t0 + p.dt);
-            return design_cyl(*p.dsg, r.cidx, tq);
+            return design_cyl_tau(*p.dsg, r.cidx, q == 0 ? cx.tau[0] : (q == 1 ? cx.tau[1] : cx.tau[2]));
         }
         return p.cyl_tab[(size_t)(3 * step + tid / t.cyl_count) * p.M + r.cidx];
     }
     return Cyl{0.0f, 0.0f, 0.0f, 0.0f};
+}
+// stage times t, t + 0.5f0*dt, t + dt of the tabulated time of `step` (src/dynamics.jl:10-13), clamped and shifted as the
+// interpolator does: what fused_cyl_fetch(step) of a tile that evaluates its cylinders itself needs
+template <int FL>
+WV_HD void fused_cyl_times(const FusedParams &p, int step, TileCtx &cx)
+{
+    if (!(FL & F_CYL) || !p.dsg || step >= p.nsteps) return;  // block-uniform
+    const float t0 = p.tspan[step];
+    cx.tau[0] = design_tau(*p.dsg, t0);
+    cx.tau[1] = design_tau(*p.dsg, t0 + p.hdt);
+    cx.tau[2] = design_tau(*p.dsg, t0 + p.dt);
 }
 template <int FL>
 WV_HD void fused_cyl_commit(const TileDesc &t, int tid, const FusedLds &lds, const TileCtx &cx, const Cyl &c)
@@ -931,6 +946,7 @@ WV_HD void fused_load(const FusedParams &p, const StepIO &io, const TileDesc &t,
 {
     fused_tile_init<AUX, FL, NW, RPT>(p, t, tid, cx, r);
     fused_step_init<FL>(p, io.step, cx);
+    fused_cyl_times<FL>(p, io.step, cx);
     fused_cyl_commit<FL>(t, tid, lds, cx, fused_cyl_fetch<AUX, FL, RPT>(p, io.step, t, tid, cx, r));
     fused_load_state<AUX, NW, RPT>(p, io.u, t, tid, r);
 }

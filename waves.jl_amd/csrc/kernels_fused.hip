@@ -238,6 +238,7 @@ __device__ WV_TILE_CALL bool run_tile_resident(const FusedParams *p0_, lds_f2_pt
         const FusedParams &p = *opaque(p0);
         const int tid = opaque((int)threadIdx.x);
         fused_tile_init<AUX, FL, NW, RPT>(p, t, tid, cx, r, dev_cull ? cull : nullptr);
+        fused_cyl_times<FL>(p, 0, cx);
         fused_cyl_commit<FL>(t, tid, lds, cx, fused_cyl_fetch<AUX, FL, RPT>(p, 0, t, tid, cx, r));  // steps[s].step == s
         fused_load_state<AUX, NW, RPT>(p, opaque(p.steps)[0].u, t, tid, r);
         if (tid == 0) *vote = 0;  // (set by a wave that gives up; read after the first barrier of a step)
@@ -259,6 +260,7 @@ __device__ WV_TILE_CALL bool run_tile_resident(const FusedParams *p0_, lds_f2_pt
     }
         WV_STAMP(0)
         fused_step_init<FL>(p, io.step, cx);
+        fused_cyl_times<FL>(p, io.step + 1, cx);  // (for the fetch of the NEXT step's cylinders at the end of this one)
         fused_publish<AUX, FL, NW, RPT, 1>(p, t, tid, lds, cx, r);
         __syncthreads();
         WV_STAMP(7)
