@@ -494,6 +494,8 @@ def main():
         else:
             sweep()
     if world > 1:
+        for en in envs:
+            en.ctx.synchronize()
         wd.gather_signals(env.signal)  # warm the communicator up outside the timed region
     # A full collection of the interpreter's cyclic GC takes 30-50 ms once torch is imported (millions of objects) and
     # would land in the middle of a 1 ms action every few hundred allocations: park everything allocated so far in the
@@ -521,16 +523,17 @@ def main():
                 kern_ms += t_["step_kernel_ms"]
                 kern_launches += t_["step_kernel_launches"]
     t_loop = time.perf_counter()
+    for en in envs:          # (the library's own sync point: a resident launch that is waiting for further actions leaves now,
+        en.ctx.synchronize()  # instead of being waited out by the collective's kernels and the device-wide synchronisation below)
+    t_sync0 = time.perf_counter()
     all_sig = wd.gather_signals(np.stack(sigs))
     t_gather = time.perf_counter()
-    for en in envs:          # (the library's own sync point: a resident launch that is waiting for further actions leaves now,
-        en.ctx.synchronize()  # instead of being waited out by the device-wide synchronisation below)
-    t_sync = time.perf_counter()
+    t_sync = t_gather
     sync_device()
     wd.barrier()
     if os.environ.get("WAVES_AMD_PYPROF") and rank == 0:
-        print(f"[bench pyprof] timed region (ms): loop {1e3 * (t_loop - t0):.3f} | gather {1e3 * (t_gather - t_loop):.3f} | ctx.synchronize "
-              f"{1e3 * (t_sync - t_gather):.3f} | device sync + barrier {1e3 * (time.perf_counter() - t_sync):.3f}", file=sys.stderr)
+        print(f"[bench pyprof] timed region (ms): loop {1e3 * (t_loop - t0):.3f} | ctx.synchronize {1e3 * (t_sync0 - t_loop):.3f} | gather "
+              f"{1e3 * (t_gather - t_sync0):.3f} | device sync + barrier {1e3 * (time.perf_counter() - t_sync):.3f}", file=sys.stderr)
     assert len(all_sig) == world
     elapsed = wd.max_over_ranks(time.perf_counter() - t0)
 
