@@ -320,6 +320,7 @@ def timed_rollout(env, policy, n_actions, in_flight=2):
         dev_ms += t["total_ms"]
         job_us.append(t["step_kernel_ms"] * 1e3 / max(t["step_kernel_launches"], 1))
 
+    with_state = getattr(timed_rollout, "with_state", False)   # --with-state: state(env) in front of every action (src/data.jl:23)
     prof = os.environ.get("WAVES_AMD_PYPROF")   # diagnostic: where the host's time per action goes (policy / begin / end)
     tp = [0.0, 0.0, 0.0]
     for k in range(n_actions):
@@ -332,6 +333,8 @@ def timed_rollout(env, policy, n_actions, in_flight=2):
             tp[0] += b - a
             tp[1] += c_ - b
         else:
+            if with_state:
+                env.state()
             env.step_begin(policy(env))
         if k > 0 or in_flight < 2:
             a = time.perf_counter()
@@ -433,6 +436,9 @@ def main():
                     help="extra (untimed-for-`value`) measurement at N=1: this many independent envs on the GPU (0 = skip)")
     ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
                     help="actions of the one env in flight (2 = pipelined, the default; 1 = plain env(action) loop)")
+    ap.add_argument("--with-state", action="store_true",
+                    help="with --in-flight 1: read state(env) (the 128x128x4 observation, resized on the device) in front of every "
+                         "action, as generate_episode! and the MPC script of the reference do")
     ap.add_argument("--side-configs", type=int, default=1, help="N=1: also time 2048^2 and 256^2 after the headline (0 = skip)")
     ap.add_argument("--stub-env", action="store_true", help=argparse.SUPPRESS)  # tests: rank logic without a GPU
     args = ap.parse_args()
@@ -511,6 +517,10 @@ def main():
     dev_ms = 0.0
     kern_ms, kern_launches = 0.0, 0
     if E == 1:
+        timed_rollout.with_state = bool(args.with_state and args.in_flight == 1 and not args.stub_env)
+        if timed_rollout.with_state:
+            env.state()   # (allocates the observation buffer outside the timed region)
+            env.ctx.synchronize()
         sigs, kern_ms, kern_launches, dev_ms = timed_rollout(env, policy, args.steps, args.in_flight)
     else:
         sigs = []
@@ -616,6 +626,7 @@ def main():
                        "in_flight": ("2 actions of the one env (host work of action k+1 under the kernel of action k)"
                                      if args.in_flight == 2 else "1 (plain env(action) loop)")
                                     if E == 1 else "4 envs at a time on their HIP streams",
+                       "state_before_every_action": bool(getattr(timed_rollout, "with_state", False)),
                        "device_ms_per_step": round(dev_ms / args.steps, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),

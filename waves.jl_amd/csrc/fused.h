@@ -109,6 +109,7 @@ bool fused_persist_alive(FusedPlan *p);
 int fused_retire(FusedPlan *p);
 bool fused_needs_stream(FusedPlan *p, bool capture, const float *G, int out2_idx);
 void fused_allow_persist(FusedPlan *p, bool allow);  // per call: false ends the launch with the call
+bool fused_obs_beside_launch(FusedPlan *p);          // a launch is waiting and leaves room for a small kernel on another stream
 double fused_last_job_ms(const FusedPlan *p);        // in-kernel duration of the resident call waited for last
 int fused_job_times(FusedPlan *p, double *ms, int cap);  // ... of the (last `cap`) resident calls since the previous query; clears
 void fused_launch_stats(const FusedPlan *p, double *ms, int *jobs);  // HIP-event duration and jobs of the launch that ended last

@@ -1615,6 +1615,14 @@ void fused_launch_stats(const FusedPlan *p, double *ms, int *jobs)
     *jobs = p->last_launch_jobs;
 }
 void fused_allow_persist(FusedPlan *p, bool allow) { p->allow_persist = allow; }
+// A launch is waiting for jobs and leaves at least 16 block slots of the device free: a small kernel on another stream
+// finds room beside it (WAVES_AMD_OBS_BESIDE=0: never)
+bool fused_obs_beside_launch(FusedPlan *p)
+{
+    const char *e = getenv("WAVES_AMD_OBS_BESIDE");  // (read per call: tests switch it)
+    if ((e && atoi(e) == 0) || !fused_persist_alive(p)) return false;
+    return device_slots(p) - p->L[p->cur_l].ntiles >= 16;
+}
 
 static int fused_run_steps(FusedPlan *pl, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s, hipEvent_t ev_start);
 
