@@ -332,6 +332,8 @@ def timed_rollout(env, policy, n_actions, in_flight=2):
             c_ = time.perf_counter()
             tp[0] += b - a
             tp[1] += c_ - b
+            if k == 0:
+                print(f"[bench pyprof] first action (us): policy {(b - a) * 1e6:.1f} | step_begin (starts the launch) {(c_ - b) * 1e6:.1f}", file=sys.stderr)
         else:
             if with_state:
                 env.state()
@@ -494,21 +496,23 @@ def main():
 
     assert len(ds.low.config) == 18 and len(ds.low.core) == 1  # every rank holds rank 0's triple-ring block
 
+    if world > 1:
+        wd.gather_signals(np.zeros(2, np.float32))  # warm the communicator up outside the timed region
+    # A full collection of the interpreter's cyclic GC takes 30-50 ms once torch is imported (millions of objects) and
+    # would land in the middle of a 1 ms action every few hundred allocations: park everything allocated so far in the
+    # permanent generation, as long-running Python services do.  In FRONT of the warm-up: the collection leaves the host's
+    # caches cold and the device idle for tens of milliseconds, which is exactly what the warm-up steps are there to undo
+    # (behind them it made the first timed action 0.3 ms slower on the host, and the first ten ran at the device's idle clocks).
+    gc.collect()
+    gc.freeze()
+    timed_rollout.with_state = bool(E == 1 and args.with_state and args.in_flight == 1 and not args.stub_env)
     for _ in range(args.warmup):
         if E == 1:
+            if timed_rollout.with_state:
+                env.state()   # (the first one allocates the observation buffers)
             env(policy(env))
         else:
             sweep()
-    if world > 1:
-        for en in envs:
-            en.ctx.synchronize()
-        wd.gather_signals(env.signal)  # warm the communicator up outside the timed region
-    # A full collection of the interpreter's cyclic GC takes 30-50 ms once torch is imported (millions of objects) and
-    # would land in the middle of a 1 ms action every few hundred allocations: park everything allocated so far in the
-    # permanent generation, as long-running Python services do.
-    gc.collect()
-    gc.freeze()
-
     for en in envs:   # the warm-up's resident launch leaves here: the timed region starts (and pays for) its own launch
         en.ctx.synchronize()
     wd.barrier()
@@ -517,10 +521,6 @@ def main():
     dev_ms = 0.0
     kern_ms, kern_launches = 0.0, 0
     if E == 1:
-        timed_rollout.with_state = bool(args.with_state and args.in_flight == 1 and not args.stub_env)
-        if timed_rollout.with_state:
-            env.state()   # (allocates the observation buffer outside the timed region)
-            env.ctx.synchronize()
         sigs, kern_ms, kern_launches, dev_ms = timed_rollout(env, policy, args.steps, args.in_flight)
     else:
         sigs = []

@@ -815,6 +815,7 @@ namespace {
 // with it on, the accumulators are shared under a mutex and the lap clock is the calling thread's own)
 struct HostProf {
     const bool on = getenv("WAVES_AMD_HOSTPROF") != nullptr;
+    const bool each = on && atoi(getenv("WAVES_AMD_HOSTPROF")) >= 2;  // =2: every call's sections as they happen
     std::mutex mu;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long calls = 0;
@@ -845,6 +846,7 @@ struct HostProf {
             std::lock_guard<std::mutex> g(mu);
             acc[k] += us;
         }
+        if (each) fprintf(stderr, "[waves_amd hostprof] call %ld section %d: %.1f us\n", calls, k, us);
         if (us > 3000.0) fprintf(stderr, "[waves_amd hostprof] section %d of wv_integrate_begin took %.1f ms\n", k, us / 1000.0);
         clock() = n;
     }
