@@ -1003,6 +1003,16 @@ int fused_prepare(FusedPlan *p, int slot, float *frames, float *ic, float *out2,
                    row_lo, row_hi);
     const size_t nt = p->hp.tiles.size();
     const size_t ni = p->idx.size() ? p->idx.size() : 1;
+    if (const char *dump = getenv("WAVES_AMD_PLAN_DUMP")) {  // diagnostic: the launch order of this call (tools/plan_balance.py)
+        if (FILE *f = fopen(dump, "w")) {
+            fprintf(f, "# cus %d slots %d RYF %d RYB %d RYP %d | pos x0 y0 ox oy aux edge cyl slot\n", p->cu_count, device_slots(p), p->hp.RYF, p->hp.RYB, p->hp.RYP);
+            for (size_t i = 0; i < nt; ++i) {
+                const TileDesc &t = p->hp.tiles[i];
+                fprintf(f, "%zu %d %d %d %d %d %d %d %d\n", i, t.x0, t.y0, t.ox, t.oy, t.aux, t.edge, t.cyl_count, t.slot);
+            }
+            fclose(f);
+        }
+    }
     // (the slot's buffers were last read by the call before the previous one, which the caller has ended)
     if (!ensure_pair(&p->d_tiles[slot], &p->h_tiles[slot], &p->tiles_cap[slot], nt, nt)) return 1;
     if (!ensure_pair(&p->d_idx[slot], &p->h_idx[slot], &p->idx_cap[slot], ni, std::max(2 * ni, nt * 16))) return 1;
