@@ -62,7 +62,14 @@ for sub in ("pmc1", "pmc2", "pmc3"):
             ids = sorted(d, key=lambda x: int(x))
             big = max(ids, key=lambda x: d[x])
             scales = c not in ("SQ_WAVES",)
-            out["counters"][c] = {"timed_dispatch": d[big], "per_action": d[big] / STEPS if scales else d[big], "dispatches": len(ids),
+            vals = sorted(d[x] for x in ids)
+            if len(ids) >= STEPS:
+                # (under --pmc the profiler serialises the process enough for a waiting launch to reach its idle limit between two
+                # actions: nearly every action then is a dispatch of its own -- the median dispatch IS one action)
+                per_action, how = vals[len(vals) // 2], "median dispatch (one action per dispatch in this pass)"
+            else:
+                per_action, how = (d[big] / STEPS if scales else d[big]), "largest dispatch / actions of the timed region"
+            out["counters"][c] = {"timed_dispatch": d[big], "per_action": per_action, "per_action_is": how, "dispatches": len(ids),
                                   "all_dispatches": [d[x] for x in ids]}
         else:
             out["counters"][c] = {"mean_per_launch": sum(d.values()) / max(1, len(d)), "launches": len(d)}

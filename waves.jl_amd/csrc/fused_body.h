@@ -324,84 +324,27 @@ WV_HD void speed_accum(const Cyl c, float x, float y, int &count, float &cd)
     cd = cd + (in ? c.c : 0.0f);
 }
 
-// A wave-uniform int, said so (device: in a scalar register, what is indexed with it is loaded through the scalar cache).
-WV_HD int wv_uniform_int(int v)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_readfirstlane(v);
-#else
-    return v;
-#endif
-}
-// element i (wave-uniform) of a table nobody writes while kernels run (coordinates): a scalar load -- as an ordinary global
-// load (the compiler cannot know that the table is constant) its latency stood at the head of the speed phase of every step
-WV_HD float wv_const_ld(const float *tab, int i)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef const float __attribute__((address_space(4))) *const_fp;
-    return ((const_fp)(unsigned long long)tab)[i];
-#else
-    return tab[i];
-#endif
-}
-// true when `b` holds in every lane of the wave (the caller knows it to be wave-uniform: a uniform branch, not an exec region)
-WV_HD bool wv_uniform_bool(bool b)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_readfirstlane((int)b) != 0;
-#else
-    return b;
-#endif
-}
-
-// One cylinder of a tile's list at the three stage times, added to the (time, row) sums of one thread.  A design that only
-// changes radii (AdjustableRadiiScatterers, the triple ring of the headline configuration) has the same centre at all three
-// times: the squared distance of a cell is then formed ONCE and compared with the three radii -- the very same values the
-// three separate evaluations would have formed, so the results cannot differ.  (The test is wave-uniform: the cylinders are
-// broadcast values.)
-template <int RPT>
-WV_HD void speed_accum3(const Cyl (&c)[3], float x, const float (&ys)[RPT], int (&count)[3][RPT], float (&cd)[3][RPT])
-{
-    const bool same = c[0].px == c[1].px && c[0].py == c[1].py && c[0].px == c[2].px && c[0].py == c[2].py;
-    if (wv_uniform_bool(same)) {
-        const float ddx = x - c[0].px;
-        const float dx2 = ddx * ddx;
-#pragma unroll
-        for (int rr = 0; rr < RPT; ++rr) {
-            const float ddy = ys[rr] - c[0].py;
-            const float d2 = dx2 + ddy * ddy;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const bool in = d2 < c[q].r2;
-                count[q][rr] += in ? 1 : 0;
-                cd[q][rr] = cd[q][rr] + (in ? c[q].c : 0.0f);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-#pragma unroll
-            for (int rr = 0; rr < RPT; ++rr) speed_accum(c[q], x, ys[rr], count[q][rr], cd[q][rr]);
-    }
-}
-
 // c^2 of the total set for the RPT rows of one thread at the three stage times of a step.  The loop over the tile's
 // cylinders is the OUTER loop and handles the three stage times together (three broadcast LDS reads in flight per
 // iteration instead of one per row and time); each (time, row) still accumulates its cylinders in ascending order,
 // exactly like sum(mask .* c, dims = 3).
 // Two loops, one per home of the list: as one loop with the choice inside, the compiler merged the LDS and the global
 // pointer into one generic pointer -- flat loads, and a wait for EVERY outstanding memory access in each iteration.
+// (Measured and not kept, round 3: ONE squared distance per cell for the three stage times of a cylinder whose centre does not
+// move -- a third fewer instructions per cylinder, bit-exact -- and the rows' y as scalar loads: -0.3 % at 700^2, but +2.7 % and
+// +1.3 % at 256^2, where the wave-uniform test and the scalar loads' latency lengthen a step that is nothing but latency.
+// What cylinders cost at 700^2 is not this arithmetic at all (skipping it altogether: -0.2 %) but the balance of the CU pairs,
+// DESIGN 6 "what the cylinders cost".)
 template <int NW, int RPT>
 WV_HD void tile_speed_sq(const FusedParams &p, const TileDesc &t, const TileCtx &cx, const FusedLds &lds, int w, float x,
                          float bsq[3][RPT])
 {
     int count[3][RPT];
     float cd[3][RPT], ys[RPT];
-    const int wu = wv_uniform_int(w);  // (the rows of a wave: their y is a scalar load)
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
-        const int gy = t.y0 - FT_H + wu + NW * rr;
-        ys[rr] = wv_const_ld(p.y, gy < 0 ? 0 : (gy >= p.ny ? p.ny - 1 : gy));
+        const int gy = t.y0 - FT_H + w + NW * rr;
+        ys[rr] = p.y[gy < 0 ? 0 : (gy >= p.ny ? p.ny - 1 : gy)];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             count[q][rr] = 0;
@@ -414,7 +357,10 @@ WV_HD void tile_speed_sq(const FusedParams &p, const TileDesc &t, const TileCtx 
             Cyl c[3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) c[q] = lds.cyl[q * t.cyl_count + k];
-            speed_accum3<RPT>(c, x, ys, count, cd);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int rr = 0; rr < RPT; ++rr) speed_accum(c[q], x, ys[rr], count[q][rr], cd[q][rr]);
         }
     } else {
         for (int k = 0; k < n; ++k) {
@@ -422,7 +368,10 @@ WV_HD void tile_speed_sq(const FusedParams &p, const TileDesc &t, const TileCtx 
             const int col = t.cyl_count < 0 ? k : p.cyl_idx[t.cyl_begin + k];
 #pragma unroll
             for (int q = 0; q < 3; ++q) c[q] = p.cyl_tab[(size_t)(3 * cx.step + q) * p.M + col];
-            speed_accum3<RPT>(c, x, ys, count, cd);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int rr = 0; rr < RPT; ++rr) speed_accum(c[q], x, ys[rr], count[q][rr], cd[q][rr]);
         }
     }
 #pragma unroll
