@@ -95,7 +95,8 @@ def lib():
     _sig(L, "wv_set_gaussian_source", [ctx, C.c_int, _fp, _fp, _fp, C.c_float])
     _sig(L, "wv_get_source_shape", [ctx, _fp])
     _sig(L, "wv_observation", [ctx, C.c_int, C.c_int, _fp])
-    _sig(L, "wv_set_design", [ctx, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_float])
+    # (the six array arguments as plain addresses: no pointer objects to build per action, see _DesignAbi)
+    _sig(L, "wv_set_design", [ctx, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float])
     _sig(L, "wv_set_design_sequence", [ctx, C.c_int, C.c_int, C.c_int, _fp, _fp])
     _sig(L, "wv_observation_action", [ctx, C.c_int, C.c_int, C.c_int, _fp])
     _sig(L, "wv_get_frames_action", [ctx, C.c_int, _fp])
@@ -145,21 +146,57 @@ def fortran(a, shape=None) -> np.ndarray:
 
 
 class _DesignAbi:
-    """One stacked design in the form wv_set_design takes: pos (M, 2) column-major, r (M,), c (M,), with their pointers.
-    Designs are immutable values and every design is handed over twice (as `final`, then as `initial`): built once."""
-    __slots__ = ("pos", "r", "c", "ptrs", "M")
+    """One stacked design in the form wv_set_design takes: pos (M, 2) column-major, r (M,), c (M,) -- ONE float32 buffer
+    [px | py | r | c] filled straight from the design's parts (a Cloak: its configuration, then its core; src/designs.jl:133-138,
+    228), and the three addresses.  Designs are immutable values and every design is handed over twice (as `final`, then as
+    `initial`): built once.  (The stacked Cylinders object, three concatenations and three pointer casts per action that this
+    replaces were a quarter of the host's time between two actions of a state-dependent loop.)"""
+    __slots__ = ("buf", "M", "ptrs")
 
-    def __init__(self, pos, r, c):
-        self.pos = fortran(np.asarray(pos, np.float32).reshape(-1, 2))
-        self.r = np.ascontiguousarray(r, np.float32).reshape(-1)
-        self.c = np.ascontiguousarray(c, np.float32).reshape(-1)
-        self.M = len(self.r)
-        assert self.pos.shape[0] == self.M and len(self.c) == self.M
-        self.ptrs = [fptr(self.pos), fptr(self.r), fptr(self.c)]
+    def __init__(self, parts):
+        M = 0
+        for q in parts:
+            M += len(q[1])
+        buf = np.empty(4 * M, np.float32)
+        o = 0
+        for pos, r, c in parts:
+            m = len(r)
+            if m == 0:
+                continue
+            pos = np.asarray(pos, np.float32).reshape(-1, 2)
+            buf[o:o + m] = pos[:, 0]
+            buf[M + o:M + o + m] = pos[:, 1]
+            buf[2 * M + o:2 * M + o + m] = r
+            buf[3 * M + o:3 * M + o + m] = c
+            o += m
+        self.buf, self.M = buf, M
+        a = buf.ctypes.data
+        self.ptrs = [a, a + 8 * M, a + 12 * M]
+
+    def __iter__(self):   # (pos, r, c) = abi: what Context.set_design also accepts as a plain tuple
+        return iter((self.pos, self.r, self.c))
+
+    def __getitem__(self, k):
+        return (self.pos, self.r, self.c)[k]
+
+    def __len__(self):
+        return 3
+
+    @property
+    def pos(self):
+        return self.buf[:2 * self.M].reshape(2, self.M).T   # (M, 2), column-major like the reference's
+
+    @property
+    def r(self):
+        return self.buf[2 * self.M:3 * self.M]
+
+    @property
+    def c(self):
+        return self.buf[3 * self.M:]
 
 
 def design_abi(pos, r, c) -> "_DesignAbi":
-    return _DesignAbi(pos, r, c)
+    return _DesignAbi([(pos, r, c)])
 
 
 def device_count() -> int:
@@ -273,7 +310,7 @@ class Context:
             return
         arrs, ptrs = [], []
         for d in (initial, final):
-            ab = getattr(d, "abi", None) or design_abi(*d)
+            ab = d if type(d) is _DesignAbi else design_abi(*d)
             arrs.append(ab)
             ptrs += ab.ptrs
         M = arrs[0].M

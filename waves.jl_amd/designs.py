@@ -282,25 +282,33 @@ class DesignInterpolator:
 
     def abi_args(self):
         """(initial, final, ti, tf) in the form Context.set_design takes."""
-        a, b = self.initial.stacked(), self.final.stacked()
+        a, b = _abi_of(self.initial), _abi_of(self.final)
         if a is None:
             return None, None, self.ti, self.tf
-        return _abi_of(a), _abi_of(b), self.ti, self.tf
+        return a, b, self.ti, self.tf
 
 
-class _AbiTuple(tuple):
-    """(pos, r, c) of a stacked design, as before, carrying the buffers Context.set_design hands to the library (built once
-    per design object: designs are immutable values and each is passed twice, as `final` and then as `initial`)."""
-    abi = None
+def _parts(design):
+    """The Cylinders a design stacks to, in order (src/designs.jl:133-138, 228), without building the stacked object."""
+    if isinstance(design, Cylinders):
+        return (design,)
+    if isinstance(design, AbstractScatterers):
+        return (design.cylinders,)
+    if isinstance(design, Cloak):
+        return (design.config.cylinders, design.core)
+    return None
 
 
-def _abi_of(cyl):
-    t = getattr(cyl, "_abi_tuple", None)
+def _abi_of(design):
+    """The design as Context.set_design takes it (unpacks as (pos, r, c)); built once per design object: designs are immutable
+    values and each is passed twice, as `final` and then as `initial`."""
+    t = getattr(design, "_abi", None)
     if t is None:
+        parts = _parts(design)
+        if parts is None:
+            return None   # NoDesign
         from . import _ffi
-        t = _AbiTuple((cyl.pos, cyl.r, cyl.c))
-        t.abi = _ffi.design_abi(cyl.pos, cyl.r, cyl.c)
-        cyl._abi_tuple = t
+        t = design._abi = _ffi._DesignAbi([(q.pos, q.r, q.c) for q in parts])
     return t
 
 
