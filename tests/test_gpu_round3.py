@@ -175,3 +175,77 @@ def test_state_of_env_in_front_of_every_action_keeps_the_launch():
     assert np.abs(got[0][-1][:, :, 2]).max() > 0
     assert t0["launch_jobs"] == 1          # every observation made the launch leave: one launch per action
     assert t1["launch_jobs"] == 6          # one launch for the whole episode
+
+
+def _spin(us):
+    t = time.perf_counter()
+    while (time.perf_counter() - t) * 1e6 < us:
+        pass
+
+
+def _soak(n_actions, seed, pattern_seed, sleeps, **kw):
+    """A mixed sequence of env calls (plain actions, two in flight, state(env) in between, a synchronize now and then), with
+    pauses around the launch's idle limit between them when `sleeps`; returns every signal and observation and the last frames."""
+    gc.collect()
+    env, pol = _env(160, 30, n_actions + 4, seed, **kw)   # (30 steps: an action of exactly 20 needs the stream for its first frame)
+    pr = np.random.default_rng(pattern_seed)
+    sigs, obs = [], []
+    k = 0
+    while k < n_actions:
+        mode = int(pr.integers(0, 4))
+        pause = float(pr.uniform(0.0, 90.0))
+        if sleeps:
+            _spin(pause)
+        if mode == 0 or k + 2 > n_actions:       # env(action)
+            env(pol(env))
+            sigs.append(env.signal.copy())
+            k += 1
+        elif mode == 1:                          # two actions in flight
+            env.step_begin(pol(env))
+            env.step_begin(pol(env))
+            if sleeps:
+                _spin(pause / 2)
+            env.step_end()
+            sigs.append(env.signal.copy())
+            env.step_end()
+            sigs.append(env.signal.copy())
+            k += 2
+        elif mode == 2:                          # state(env) in front of the action
+            obs.append(np.array(env.state().wave))
+            env(pol(env))
+            sigs.append(env.signal.copy())
+            k += 1
+        else:                                    # the launch is told to leave
+            env.ctx.synchronize()
+            env(pol(env))
+            sigs.append(env.signal.copy())
+            k += 1
+    frames = np.array(env.ctx.get_frames())
+    res = env.ctx.timing()["resident"]
+    env.ctx.close()
+    return sigs, obs, frames, res
+
+
+@pytest.mark.parametrize("idle_us,pattern", [("40", 7), ("15", 8), ("70", 9)])
+def test_soak_launch_leaves_and_returns_around_its_idle_limit(monkeypatch, idle_us, pattern):
+    """The job protocol under the timing it is most exposed to: a launch whose idle limit (15-70 us) lies inside the host's
+    pauses (0-90 us), so that calls find the launch waiting, leaving, or just gone -- fused_job_wait's relaunch of a job that
+    was rung as the launch left included.  Same calls without pauses and with the default limit: the same bytes; and the
+    staged kernels (an independent implementation of the step): the same frames and observations."""
+    n = 120
+    monkeypatch.setenv("WAVES_AMD_IDLE_US", idle_us)
+    s1, o1, f1, r1 = _soak(n, 300 + pattern, pattern, True)
+    monkeypatch.delenv("WAVES_AMD_IDLE_US")
+    s2, o2, f2, r2 = _soak(n, 300 + pattern, pattern, False)
+    s3, o3, f3, r3 = _soak(n, 300 + pattern, pattern, False, impl="staged")
+    assert r1 and r2 and not r3
+    assert len(s1) == len(s2) == len(s3) == n and len(o1) == len(o2) == len(o3) > 10
+    for a, b in zip(s1, s2):
+        assert np.array_equal(a, b)
+    for a, b in zip(o1, o2):
+        assert np.array_equal(a, b)
+    assert np.array_equal(f1, f2) and np.array_equal(f1, f3)
+    for a, b in zip(o1, o3):
+        assert np.array_equal(a, b)
+    for a, b in zip(s1, s3):
+        assert rel_err(a[:, :2], b[:, :2]) < ENERGY_RTOL
