@@ -71,3 +71,13 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "waves_oracle" not in txt and "c_oracle" not in txt and "oracle/" not in txt, f
+
+
+def test_c_host_example_builds_against_the_header_alone():
+    """examples/host_loop.cpp -- the env(action) loop written against include/waves_amd.h with plain g++ (no HIP headers on
+    the caller's side) -- compiles and links against the library (it is RUN in the GPU tests)."""
+    import subprocess
+    csrc = os.path.dirname(w.build())
+    r = subprocess.run(["make", "-C", csrc, "example"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert os.path.exists(os.path.join(os.path.dirname(os.path.dirname(csrc)), "examples", "host_loop"))

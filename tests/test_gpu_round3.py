@@ -249,3 +249,20 @@ def test_soak_launch_leaves_and_returns_around_its_idle_limit(monkeypatch, idle_
         assert np.array_equal(a, b)
     for a, b in zip(s1, s3):
         assert rel_err(a[:, :2], b[:, :2]) < ENERGY_RTOL
+
+
+def test_c_host_loop_over_the_abi_alone():
+    """examples/host_loop.cpp: the env(action) loop from a compiled host through the C ABI only.  One action at a time, two in
+    flight and with state(env) in front of every action it integrates the same actions: the same traces (checksum), on the
+    resident kernel, every action served by the launch that was already there."""
+    exe = os.path.join(ROOT, "examples", "host_loop")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "waves.jl_amd", "csrc"), "example"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    outs = []
+    for args in (["320", "12", "1", "0"], ["320", "12", "2", "0"], ["320", "12", "1", "1"]):
+        p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    assert all(o["resident"] == 1 for o in outs)
+    assert outs[0]["signal_checksum"] == outs[1]["signal_checksum"] == outs[2]["signal_checksum"] != 0
+    assert all(o["last_launch_jobs"] == 12 for o in outs), outs   # one launch served the whole timed region
