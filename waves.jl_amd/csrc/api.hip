@@ -61,6 +61,11 @@ struct wv_ctx {
     size_t obs_cap = 0;
     float *h_obs = nullptr;    // ... in pinned host memory, written by the kernel itself when it runs beside a waiting launch
     size_t h_obs_cap = 0;
+    // state(env) produced by the resident job itself (FusedParams::ob_out): once wv_observation has been asked for a resolution,
+    // the following calls deliver the observation of the frames they leave into their slot's pinned buffer
+    int obs_auto_rx = 0, obs_auto_ry = 0;  // the resolution to produce (0: nobody has asked, or nobody has used the last ones)
+    int obs_slot = -1;                     // slot whose h_obs holds state(env) of the CURRENT frames, or -1
+    int obs_unused = 0;                    // observations produced since the last one that was asked for
     // capture_frames == 2 of a design sequence: the three frames of every action but the last (those are env.wave itself)
     float *d_seq_frames = nullptr;
     size_t seq_frames_cap = 0;
@@ -90,6 +95,9 @@ struct wv_ctx {
         size_t traj_cap = 0;
         hipEvent_t copy_ev = nullptr;                // the copy of the planes to h_traj has finished
         hipEvent_t ev1 = nullptr;                    // after the last device work of the call
+        float *h_obs = nullptr;                      // pinned: state(env) of the frames this call leaves, written by its job
+        size_t h_obs_cap = 0;
+        int obs_rx = 0, obs_ry = 0;                  // ... at this resolution (0: this call produces none)
         bool capture_all = false;                    // capture_frames == 2
         std::vector<hipEvent_t> kev;                 // kev[0] / kev[1] bracket the integrator launch(es); more when profiling
         // what running the call once more needs (after the resident kernel gave it up)
@@ -339,6 +347,8 @@ int wv_destroy(wv_ctx *c)
     for (float *b : c->h_stream)
         if (b) (void)hipHostFree(b);
     if (c->h_obs) (void)hipHostFree(c->h_obs);
+    for (wv_ctx::Slot &q : c->slot)
+        if (q.h_obs) (void)hipHostFree(q.h_obs);
     if (c->fused) fused_destroy(c->fused);
     if (c->up_ev) (void)hipEventDestroy(c->up_ev);
     if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
@@ -488,6 +498,7 @@ int wv_get_cell_area(wv_ctx *c, float *dOmega)
 int wv_set_frames(wv_ctx *c, const float *wave)
 {
     CHECK_CTX(c);
+    c->obs_slot = -1;  // (what state(env) shows changes)
     QUIET(c);
     if (!wave) return fail(c, WV_ERR_INVALID, "wv_set_frames: NULL");
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_set_frames: an integrate is pending");
@@ -513,6 +524,7 @@ int wv_get_frames(wv_ctx *c, float *wave)
 int wv_set_state(wv_ctx *c, const float *u)
 {
     CHECK_CTX(c);
+    c->obs_slot = -1;  // (what state(env) shows changes)
     QUIET(c);
     if (!u) return fail(c, WV_ERR_INVALID, "wv_set_state: NULL");
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_set_state: an integrate is pending");
@@ -536,6 +548,7 @@ int wv_get_state(wv_ctx *c, float *u)
 int wv_reset(wv_ctx *c)
 {
     CHECK_CTX(c);
+    c->obs_slot = -1;  // (what state(env) shows changes)
     QUIET(c);
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_reset: an integrate is pending");
     c->cur2 = 0;
@@ -549,6 +562,7 @@ int wv_reset(wv_ctx *c)
 int wv_set_source_shape(wv_ctx *c, const float *shape, float freq)
 {
     CHECK_CTX(c);
+    c->obs_slot = -1;  // (what state(env) shows changes)
     QUIET(c);
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_set_source_shape: an integrate is pending");
     c->has_source = shape != nullptr;
@@ -566,6 +580,7 @@ int wv_set_source_shape(wv_ctx *c, const float *shape, float freq)
 int wv_set_gaussian_source(wv_ctx *c, int K, const float *mu, const float *sigma, const float *a, float freq)
 {
     CHECK_CTX(c);
+    c->obs_slot = -1;  // (what state(env) shows changes)
     QUIET(c);
     if (K < 1 || !mu || !sigma || !a) return fail(c, WV_ERR_INVALID, "wv_set_gaussian_source: bad arguments");
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_set_gaussian_source: an integrate is pending");
@@ -603,6 +618,20 @@ int wv_observation(wv_ctx *c, int rx, int ry, float *out)
         return fail(c, WV_ERR_INVALID, "wv_observation: resolution must be within 1 .. grid size (src/env.jl:52)");
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_observation: an integrate is pending");
     const size_t n = (size_t)rx * ry * 4;
+    // The call that ended last has produced this very observation itself (k_steps_resident, FusedParams::ob_out): it is in
+    // pinned memory already.
+    const char *oij = getenv("WAVES_AMD_OBS_IN_JOB");  // (read per call: tests switch it)
+    const bool obs_in_job = !(oij && atoi(oij) == 0);
+    if (c->obs_slot >= 0 && !c->frames_exposed && c->slot[c->obs_slot].obs_rx == rx && c->slot[c->obs_slot].obs_ry == ry) {
+        memcpy(out, c->slot[c->obs_slot].h_obs, n * sizeof(float));
+        c->obs_unused = 0;
+        return WV_OK;
+    }
+    if (obs_in_job) {  // from now on the calls produce it (until eight in a row have gone unused)
+        c->obs_auto_rx = rx;
+        c->obs_auto_ry = ry;
+        c->obs_unused = 0;
+    }
     // state(env) in front of every action (src/data.jl:23, scripts/mpc.jl:83-85) must not cost the rollout its resident launch:
     // while one waits on the context's stream -- every call it was given has been ended, so the frames are complete in
     // memory -- the resize kernel runs on a stream of its own, on block slots the launch leaves free (it never takes them
@@ -630,6 +659,14 @@ int wv_observation(wv_ctx *c, int rx, int ry, float *out)
         c->h_obs_cap = 0;
         HIPCHK(c, hipHostMalloc((void **)&c->h_obs, n * sizeof(float), hipHostMallocDefault));
         c->h_obs_cap = n;
+    }
+    for (wv_ctx::Slot &q : c->slot) {  // (and the calls' own buffers: allocated here, where no launch is on the device)
+        if (!obs_in_job || n <= q.h_obs_cap) continue;
+        if (q.h_obs) (void)hipHostFree(q.h_obs);
+        q.h_obs = nullptr;
+        q.h_obs_cap = 0;
+        HIPCHK(c, hipHostMalloc((void **)&q.h_obs, n * sizeof(float), hipHostMallocDefault));
+        q.h_obs_cap = n;
     }
     if (!c->obs_ev) HIPCHK(c, hipEventCreateWithFlags(&c->obs_ev, hipEventDisableTiming));
     launch_observation(c->grid, frame(c, 0), frame(c, 1), frame(c, 2), c->has_source ? c->d_G : nullptr, rx, ry, c->d_obs, c->stream);
@@ -896,6 +933,7 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     const int impl = c->cfg.impl == WV_IMPL_STAGED ? WV_IMPL_STAGED : WV_IMPL_FUSED;  // AUTO -> fused
     const int si = c->next_slot;
     wv_ctx::Slot &q = c->slot[si];
+    c->obs_slot = -1;  // (the frames are about to change)
     // The copy stream is created when first needed, and only by a context that has its device to itself: HIP multiplexes
     // the streams of a process over a few hardware queues, and with several environments per GPU (one stream each) extra
     // streams make kernels of different environments queue behind each other (8 envs: 45 -> 35 Gcell-updates/s).
@@ -1158,10 +1196,17 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
         // itself, straight into q.h_signal, and is timed by its own clock stamps); the single-step path puts its launches
         // between two events.
         const FusedEnergy ef{row0, q.d_epart, want_signal ? q.h_signal : nullptr, c->dOmega};
+        // state(env) of the frames this call leaves, by the job itself, when the caller has been asking for it
+        const size_t nob = (size_t)c->obs_auto_rx * c->obs_auto_ry * 4;
+        const bool with_obs = nob > 0 && nob <= q.h_obs_cap && seq_n == 0 && !c->frames_exposed;
+        const FusedObs ob{frame(c, 0), frame(c, 1), other2(c), c->has_source ? c->d_G : nullptr, with_obs ? q.h_obs : nullptr,
+                          c->obs_auto_rx, c->obs_auto_ry};
+        q.obs_rx = with_obs ? c->obs_auto_rx : 0;
+        q.obs_ry = with_obs ? c->obs_auto_ry : 0;
         int fr = -1;
         if (dev_mode) {
             const FusedDevTables dev{M, c->d0.data(), c->d1.data(), c->ti, c->tf, tspan, c->has_source ? q.h_sfac : nullptr, t_lo, t_hi};
-            fr = fused_run(c->fused, si, fcall, c->fsteps.data(), (int)c->fsteps.size(), st, up, ef, may_stay, q.kev[0], q.kev[1], &dev);
+            fr = fused_run(c->fused, si, fcall, c->fsteps.data(), (int)c->fsteps.size(), st, up, ef, may_stay, q.kev[0], q.kev[1], &dev, &ob);
             if (fr == 3) {  // not a call for the resident kernel after all (more tiles than the device holds, shared device, ...)
                 dev_mode = false;
                 build_tables(true);
@@ -1169,9 +1214,10 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
                 if (rc) return rc;
             }
         }
-        if (!dev_mode) fr = fused_run(c->fused, si, fcall, c->fsteps.data(), (int)c->fsteps.size(), st, up, ef, may_stay, q.kev[0], q.kev[1]);
+        if (!dev_mode) fr = fused_run(c->fused, si, fcall, c->fsteps.data(), (int)c->fsteps.size(), st, up, ef, may_stay, q.kev[0], q.kev[1], nullptr, &ob);
         if (fr != 0) return fail(c, WV_ERR_HIP, std::string("fused_run failed: ") + hipGetErrorString(hipGetLastError()));
         q.resident = fused_last_resident(c->fused);
+        if (!q.resident) q.obs_rx = q.obs_ry = 0;  // (the single-step kernels produce no observation)
         q.bracketed = !q.resident;
         if (q.resident) q.prof_launches = 1;
     } else if (impl == WV_IMPL_FUSED) {
@@ -1362,6 +1408,14 @@ int wv_integrate_end(wv_ctx *c, float *signal, float *u_tot, float *u_inc)
     }
     q.pending = false;
     c->n_pending--;
+    // state(env) of the frames this call leaves is in the slot's pinned buffer when its job produced it (not after a give-up:
+    // the single-step kernels ran the call then); it is the CURRENT one only while no other call is pending
+    if (q.obs_rx > 0 && job_ms >= 0.0 && c->n_pending == 0) {
+        c->obs_slot = si;
+        if (++c->obs_unused > 8) c->obs_auto_rx = c->obs_auto_ry = 0;  // nobody reads them any more: stop producing them
+    } else {
+        c->obs_slot = -1;
+    }
     if (signal) memcpy(signal, q.h_signal, (size_t)(n + 1) * 3 * sizeof(float));
     if (q.streamed) {  // (the planes are already in host memory; callers that can read them in place use wv_integrate_end_view)
         if (u_tot) memcpy(u_tot, q.h_traj, tp * sizeof(float));
@@ -1490,6 +1544,7 @@ int wv_synchronize(wv_ctx *c)
 int wv_device_frames(wv_ctx *c, void **dptr, size_t *bytes)
 {
     CHECK_CTX(c);
+    c->obs_slot = -1;  // (what state(env) shows changes)
     QUIET(c);
     if (!dptr) return fail(c, WV_ERR_INVALID, "wv_device_frames: NULL");
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_device_frames: an integrate is pending");
@@ -1510,6 +1565,7 @@ int wv_device_frames(wv_ctx *c, void **dptr, size_t *bytes)
 int wv_release_device_frames(wv_ctx *c)
 {
     CHECK_CTX(c);
+    c->obs_slot = -1;  // (what state(env) shows changes)
     QUIET(c);
     if (c->n_pending) return fail(c, WV_ERR_STATE, "wv_release_device_frames: an integrate is pending");
     c->frames_exposed = false;

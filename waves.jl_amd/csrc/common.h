@@ -39,6 +39,27 @@ __device__ __forceinline__ float speed_at(float x, float y, const Cyl *__restric
     return C0 + cd;
 }
 
+// One element of state(env) (src/env.jl:132-137): channel `src` resized to rx x ry at pixel (i, j).  The rule is stated at
+// k_observation (kernels_aux.hip); one function, because the resident kernel also produces observations itself at the end of
+// an action (FusedParams::ob_out) and the two must agree bit for bit.  `ld(k)` reads element k of the channel.
+template <class Ld>
+__device__ __forceinline__ float obs_pixel(Ld ld, int nx, int ny, int rx, int ry, int i, int j)
+{
+    const double sx = (double)nx / (double)rx, sy = (double)ny / (double)ry;
+    double xo = sx * ((double)(i + 1) - 0.5) + 0.5 - 1.0;  // 0-based coordinate in the original
+    double yo = sy * ((double)(j + 1) - 0.5) + 0.5 - 1.0;
+    xo = xo < 0.0 ? 0.0 : (xo > (double)(nx - 1) ? (double)(nx - 1) : xo);
+    yo = yo < 0.0 ? 0.0 : (yo > (double)(ny - 1) ? (double)(ny - 1) : yo);
+    const int i0 = (int)floor(xo), j0 = (int)floor(yo);
+    const int i1 = i0 + 1 < nx ? i0 + 1 : nx - 1, j1 = j0 + 1 < ny ? j0 + 1 : ny - 1;
+    const double fx = xo - (double)i0, fy = yo - (double)j0;
+    const double a00 = ld((size_t)j0 * nx + i0), a10 = ld((size_t)j0 * nx + i1);
+    const double a01 = ld((size_t)j1 * nx + i0), a11 = ld((size_t)j1 * nx + i1);
+    const double lo = (1.0 - fx) * a00 + fx * a10;
+    const double hi = (1.0 - fx) * a01 + fx * a11;
+    return (float)((1.0 - fy) * lo + fy * hi);
+}
+
 // wave64 sum, returned to every lane.  Six DPP adds (butterfly inside a row of 16 lanes, then row broadcasts) instead of
 // six dependent LDS-crossbar shuffles: the sum of a wave is on the critical path between two steps of k_steps_resident.
 // The order of the additions is fixed, so results are deterministic (cdna_hip_programming.md Appendix B "Reduction").

@@ -78,6 +78,13 @@ struct FusedEnergy {
     float *signal;
     float dOmega;
 };
+// state(env) of the frames a call leaves, produced by the resident kernel itself at the end of the job (FusedParams::ob_*):
+// out = PINNED HOST memory [4][ry][rx] or nullptr (not wanted), f0..f2 = where the three frames will be, G = source shape or nullptr.
+struct FusedObs {
+    const float *f0, *f1, *f2, *G;
+    float *out;
+    int rx, ry;
+};
 // all steps of a call: one JOB of the resident kernel when the tiles fit the device at once (fused_body.h, "jobs": the
 // launch may outlive the call and serve the next ones), else a cached hipGraph of single-step kernel nodes
 // (WAVES_AMD_FUSED_GRAPH=0: eager launches).  `up`: the stream the call's tables were uploaded on.  keep: the resident
@@ -85,11 +92,12 @@ struct FusedEnergy {
 // resident path, whose durations come from the launch's own events and the kernel's clock stamps).  Returns 0 on success.
 int fused_run(FusedPlan *p, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s, hipStream_t up,
               const FusedEnergy &ef, bool keep, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
-              const FusedDevTables *dev = nullptr);
+              const FusedDevTables *dev = nullptr, const FusedObs *ob = nullptr);
 // Resident path only.  Returns 0 when the job was handed over, -1 when this call cannot take that path (more tiles than
 // the device holds at once, a single step, ...; the caller then launches step by step), 1 on a HIP error.
 int fused_try_resident(FusedPlan *p, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s,
-                       hipStream_t up, const FusedEnergy &ef, bool keep, const FusedDevTables *dev = nullptr);
+                       hipStream_t up, const FusedEnergy &ef, bool keep, const FusedDevTables *dev = nullptr,
+                       const FusedObs *ob = nullptr);
 // With `dev` (only for a call that is handed to a resident launch which is already there: fused_persist_alive, and
 // fused_dev_tables_ok) the tiles evaluate the DesignInterpolator and cull their cylinders themselves; the caller then has
 // built no cylinder table, uploaded nothing and called fused_prepare_light instead of fused_prepare.  Returns 3 when the

@@ -158,7 +158,15 @@ struct FusedParams {
     const float *tspan;        // [nsteps + 1]
     int dev_cull;              // the tiles also find out themselves which cylinders can reach them (device_cull_keep; cyl_idx unused)
     float cull_t_lo, cull_t_hi;  // the earliest / the latest stage time of the call
+    // state(env) of the frames this job leaves (src/env.jl:132-137), produced by the job itself behind its end-of-job barrier
+    // (the last JOB_OBS_BLOCKS blocks of the launch order, k_observation's arithmetic: common.h obs_pixel): a caller that looks
+    // at the state in front of every action then needs no kernel of its own for it.  ob_out: PINNED HOST memory
+    // [4][ob_ry][ob_rx] or nullptr (not wanted); ob_f0..2: the three frames as they will be after the job, ob_G the source shape or nullptr.
+    const float *ob_f0, *ob_f1, *ob_f2, *ob_G;
+    float *ob_out;
+    int ob_rx, ob_ry;
 };
+constexpr int JOB_OBS_BLOCKS = 128;  // blocks that share the observation of a job (65 536 elements at 128 x 128: one per thread)
 
 // ---- jobs: the resident launch that outlives the action ---------------------------------------------------------------
 // One launch of k_steps_resident serves a SEQUENCE of wv_integrate calls ("jobs").  The host describes job `seq` in pinned

@@ -138,26 +138,11 @@ __global__ __launch_bounds__(TPB) void k_observation(const float *__restrict__ f
                                                      int ny, int rx, int ry, float *__restrict__ out)
 {
     const size_t total = (size_t)rx * ry * 4;
-    const double sx = (double)nx / (double)rx, sy = (double)ny / (double)ry;
     for (size_t q = (size_t)blockIdx.x * TPB + threadIdx.x; q < total; q += (size_t)gridDim.x * TPB) {
         const int i = (int)(q % rx), j = (int)((q / rx) % ry), ch = (int)(q / ((size_t)rx * ry));
         const float *src = ch == 0 ? f0 : (ch == 1 ? f1 : (ch == 2 ? f2 : G));
-        if (!src) {  // NoSource: the shape channel is zero
-            out[q] = 0.0f;
-            continue;
-        }
-        double xo = sx * ((double)(i + 1) - 0.5) + 0.5 - 1.0;  // 0-based coordinate in the original
-        double yo = sy * ((double)(j + 1) - 0.5) + 0.5 - 1.0;
-        xo = xo < 0.0 ? 0.0 : (xo > (double)(nx - 1) ? (double)(nx - 1) : xo);
-        yo = yo < 0.0 ? 0.0 : (yo > (double)(ny - 1) ? (double)(ny - 1) : yo);
-        const int i0 = (int)floor(xo), j0 = (int)floor(yo);
-        const int i1 = i0 + 1 < nx ? i0 + 1 : nx - 1, j1 = j0 + 1 < ny ? j0 + 1 : ny - 1;
-        const double fx = xo - (double)i0, fy = yo - (double)j0;
-        const double a00 = src[(size_t)j0 * nx + i0], a10 = src[(size_t)j0 * nx + i1];
-        const double a01 = src[(size_t)j1 * nx + i0], a11 = src[(size_t)j1 * nx + i1];
-        const double lo = (1.0 - fx) * a00 + fx * a10;
-        const double hi = (1.0 - fx) * a01 + fx * a11;
-        out[q] = (float)((1.0 - fy) * lo + fy * hi);
+        // NoSource: the shape channel is zero
+        out[q] = src ? obs_pixel([src](size_t k) { return src[k]; }, nx, ny, rx, ry, i, j) : 0.0f;
     }
 }
 

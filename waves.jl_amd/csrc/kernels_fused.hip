@@ -442,6 +442,20 @@ __device__ __forceinline__ void job_energy_row(const FusedParams &p, int row, do
     __syncthreads();  // (red is reused by the block's next row)
 }
 
+// This block's share of state(env) (src/env.jl:132-137) of the frames the job leaves: k_observation's arithmetic (obs_pixel),
+// read past this CU's L1 (the frames were written by other blocks of this launch), written straight to pinned host memory.
+__device__ __forceinline__ void job_observation(const FusedParams &p, int rb, int nob)
+{
+    const int rx = p.ob_rx, ry = p.ob_ry;
+    const size_t total = (size_t)rx * ry * 4;
+    for (size_t q = (size_t)rb * 512 + threadIdx.x; q < total; q += (size_t)nob * 512) {
+        const int i = (int)(q % rx), j = (int)((q / rx) % ry), ch = (int)(q / ((size_t)rx * ry));
+        const float *src = ch == 0 ? p.ob_f0 : (ch == 1 ? p.ob_f1 : (ch == 2 ? p.ob_f2 : p.ob_G));
+        const float v = src ? obs_pixel([src](size_t k) { return job_ld_agentf(src + k); }, p.nx, p.ny, rx, ry, i, j) : 0.0f;
+        job_st_sysf(p.ob_out + q, v);
+    }
+}
+
 template <int NW, int RF, int RB, int RP>
 __global__ __launch_bounds__(NW * 64, 4) void k_steps_resident(JobArgs a_)
 {
@@ -585,7 +599,10 @@ __global__ __launch_bounds__(NW * 64, 4) void k_steps_resident(JobArgs a_)
         const int nrows = p.ef_signal ? p.nsteps + 1 : 0;
         const int rb = p.ntiles - 1 - b;
         for (int row = rb; row < nrows; row += p.ntiles) job_energy_row(p, row, reinterpret_cast<double *>(raw));
-        if (rb < nrows) {  // my rows are in host memory (the host looks at these words, nobody on the device waits for them)
+        // state(env) of the frames this job leaves, when asked for: the same blocks, one element per thread and pass
+        const int nob = p.ob_out ? (p.ntiles < JOB_OBS_BLOCKS ? p.ntiles : JOB_OBS_BLOCKS) : 0;
+        if (rb < nob) job_observation(p, rb, nob);
+        if (rb < nrows || rb < nob) {  // my rows are in host memory (the host looks at these words, nobody on the device waits for them)
             job_drain();
             __syncthreads();
             if (threadIdx.x == 0) job_st_sys(&a.back->rowdone[rb], seq);
@@ -1368,7 +1385,7 @@ static int jobs_launch(FusedPlan *pl, unsigned first_seq, int ntiles, hipStream_
 // `up`: the stream the caller's uploads of this call went to (its tables must have arrived before the job may start);
 // `ef`: where the trace goes.  keep: the launch may stay on the device after the job (see FusedPlan::persist).
 int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s,
-                       hipStream_t up, const FusedEnergy &ef, bool keep, const FusedDevTables *dev)
+                       hipStream_t up, const FusedEnergy &ef, bool keep, const FusedDevTables *dev, const FusedObs *ob)
 {
     pl->cur = slot;
     const size_t nt = pl->hp.tiles.size();
@@ -1456,6 +1473,11 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
     p.ef_epart = ef.epart;
     p.ef_signal = ef.signal;
     p.ef_dOmega = ef.dOmega;
+    if (ob && ob->out) {
+        p.ob_f0 = ob->f0, p.ob_f1 = ob->f1, p.ob_f2 = ob->f2, p.ob_G = ob->G;
+        p.ob_out = ob->out;
+        p.ob_rx = ob->rx, p.ob_ry = ob->ry;
+    }
     p.ctl = pl->d_ctl;
     static const bool joblog_ = getenv("WAVES_AMD_JOBLOG") != nullptr;
     p.back = joblog_ ? pl->back : nullptr;
@@ -1508,7 +1530,19 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
     desc.p = p;
     __atomic_store_n(&pl->mail->bell, pl->seq, __ATOMIC_RELEASE);
     if (!alive) {
-        const int rc = jobs_launch(pl, pl->seq, (int)nt, s);
+        // The new launch starts with this job -- unless the call before it is still pending and was rung just as the previous
+        // launch left on its idle limit without taking it (two in flight; found by the soak test: begun with this job, the new
+        // launch skipped the other one, whose wv_integrate_end then took this job's completion for its own).  A pending call
+        // that a launch is still WORKING on (one that ends with its job) is not meant: that launch says so (exit_seq / status).
+        unsigned first = pl->seq;
+        {
+            const unsigned other = pl->job_seq[slot ^ 1];
+            const int lo = pl->cur_l;
+            if (other != 0 && other + 1u == pl->seq && back_status(pl, lo) == JOBS_EXIT_IDLE &&
+                __atomic_load_n(&pl->back->exit_seq[lo], __ATOMIC_ACQUIRE) == other && !job_reached(back_done(pl), other))
+                first = other;
+        }
+        const int rc = jobs_launch(pl, first, (int)nt, s);
         if (rc != 0) {
             pl->seq--;  // (nobody has seen the description)
             __atomic_store_n(&pl->mail->bell, pl->seq, __ATOMIC_RELEASE);
@@ -1523,7 +1557,8 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
     pl->job_seq[slot] = pl->seq;
     pl->job_launch[slot] = pl->cur_l;
     pl->job_keep[slot] = p.last == 0;
-    pl->job_rows[slot] = ef.signal ? std::min(nsteps + 1, (int)nt) : 0;
+    // (blocks that report through JobBack::rowdone: the ones with trace rows and the ones with a share of the observation)
+    pl->job_rows[slot] = std::max(ef.signal ? std::min(nsteps + 1, (int)nt) : 0, (ob && ob->out) ? std::min(JOB_OBS_BLOCKS, (int)nt) : 0);
     pl->abort_pending[slot] = true;
     return 0;
 }
@@ -1637,9 +1672,9 @@ bool fused_obs_beside_launch(FusedPlan *p)
 static int fused_run_steps(FusedPlan *pl, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s, hipEvent_t ev_start);
 
 int fused_run(FusedPlan *pl, int slot, const FusedCall &call, const FusedStep *steps, int nsteps, hipStream_t s, hipStream_t up,
-              const FusedEnergy &ef, bool keep, hipEvent_t ev_start, hipEvent_t ev_stop, const FusedDevTables *dev)
+              const FusedEnergy &ef, bool keep, hipEvent_t ev_start, hipEvent_t ev_stop, const FusedDevTables *dev, const FusedObs *ob)
 {
-    const int rr = fused_try_resident(pl, slot, call, steps, nsteps, s, up, ef, keep, dev);
+    const int rr = fused_try_resident(pl, slot, call, steps, nsteps, s, up, ef, keep, dev, ob);
     if (dev && rr != 0) return rr > 0 ? rr : 1;  // (a call without host tables has no other way to run)
     pl->cur = slot;
     pl->last_resident = rr == 0;
