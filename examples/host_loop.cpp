@@ -110,9 +110,9 @@ int main(int argc, char **argv)
     CK(wv_get_timing(ctx, &t));
     const double per = ms / actions, cells = (double)n * n * steps;
     printf("{\"host\": \"C++ over the C ABI (examples/host_loop.cpp)\", \"grid\": %d, \"actions\": %d, \"in_flight\": %d, \"state_before_every_action\": %d, "
-           "\"ms_per_action\": %.4f, \"Mcell_updates_per_s\": %.1f, \"whole_job_frac_of_8TBs_at_104B\": %.4f, \"resident\": %d, "
+           "\"ms_per_action\": %.4f, \"Mcell_updates_per_s\": %.1f, \"whole_job_frac_of_8TBs_at_104B\": %.4f, \"resident\": %d, \"gave_up\": %d, "
            "\"last_launch_ms\": %.4f, \"last_launch_jobs\": %d, \"signal_checksum\": %.6g}\n",
-           n, actions, in_flight, with_state, per, cells / per / 1e3, 104.0 * cells / (per * 1e-3) / 8e12, t.resident, t.launch_ms, t.launch_jobs,
+           n, actions, in_flight, with_state, per, cells / per / 1e3, 104.0 * cells / (per * 1e-3) / 8e12, t.resident, t.gave_up, t.launch_ms, t.launch_jobs,
            checksum);
     CK(wv_destroy(ctx));
     return 0;

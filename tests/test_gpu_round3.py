@@ -310,6 +310,7 @@ def test_c_host_loop_over_the_abi_alone():
         p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stdout + p.stderr
         outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
-    assert all(o["resident"] == 1 for o in outs)
+        outs[-1]["stderr"] = p.stderr[-400:]
+    assert all(o["resident"] == 1 for o in outs), outs
     assert outs[0]["signal_checksum"] == outs[1]["signal_checksum"] == outs[2]["signal_checksum"] != 0
     assert all(o["last_launch_jobs"] == 12 for o in outs), outs   # one launch served the whole timed region

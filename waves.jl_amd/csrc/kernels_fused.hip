@@ -753,7 +753,16 @@ struct FusedPlan {
     JobMail *mail = nullptr;      // pinned host memory
     JobBack *back = nullptr;      // pinned host memory
     JobCtl *d_ctl = nullptr;
-    const TileDesc *launch_tiles = nullptr;  // the (device) tile table the newest job with a host-built table was given
+    const TileDesc *launch_tiles = nullptr;  // the (device) tile table the newest job with a host-built table was given:
+                                             // what a later call WITHOUT a table of its own (FusedDevTables) reads.  A copy of
+                                             // its own, alternating between two buffers: the per-slot table it was copied from is
+                                             // overwritten by the slot's next call -- possibly while such a job is still
+                                             // starting (a compiled host begins the next call microseconds later: its tiles
+                                             // then read two different launch orders, a tile is run twice, another not at
+                                             // all, and the launch gives up)
+    TileDesc *d_snap[2] = {nullptr, nullptr};
+    size_t snap_cap[2] = {0, 0};
+    int snap_w = -1;                         // the copy this call's fused_prepare has just filled (-1: none)
     int ctl_tiles = 0;            // tiles the flag arrays behind d_ctl were sized for
     unsigned seq = 0;             // jobs described so far (job numbers start at 1)
     // Launches: at most two are known at a time -- the newest, and the one before it while it still runs (a launch that ends
@@ -843,6 +852,7 @@ void fused_destroy(FusedPlan *p)
         if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < 2; ++k) {
         if (p->d_tiles[k]) (void)hipFree(p->d_tiles[k]);
+        if (p->d_snap[k]) (void)hipFree(p->d_snap[k]);
         if (p->h_tiles[k]) (void)hipHostFree(p->h_tiles[k]);
         if (p->d_idx[k]) (void)hipFree(p->d_idx[k]);
         if (p->h_idx[k]) (void)hipHostFree(p->h_idx[k]);
@@ -1036,6 +1046,18 @@ int fused_prepare(FusedPlan *p, int slot, float *frames, float *ic, float *out2,
     memcpy(p->h_tiles[slot], p->hp.tiles.data(), nt * sizeof(TileDesc));
     if (!p->idx.empty()) memcpy(p->h_idx[slot], p->idx.data(), p->idx.size() * sizeof(int));
     if (hipMemcpyAsync(p->d_tiles[slot], p->h_tiles[slot], nt * sizeof(TileDesc), hipMemcpyHostToDevice, up) != hipSuccess) return 1;
+    {   // ... and the copy for later calls without a table: into the buffer that is NOT the current launch_tiles (a pending job may be reading that)
+        const int w = (p->launch_tiles != nullptr && p->launch_tiles == p->d_snap[0]) ? 1 : 0;
+        if (nt > p->snap_cap[w]) {
+            if (p->d_snap[w]) (void)hipFree(p->d_snap[w]);
+            p->d_snap[w] = nullptr;
+            p->snap_cap[w] = 0;
+            if (hipMalloc((void **)&p->d_snap[w], nt * sizeof(TileDesc)) != hipSuccess) return 1;
+            p->snap_cap[w] = nt;
+        }
+        if (hipMemcpyAsync(p->d_snap[w], p->h_tiles[slot], nt * sizeof(TileDesc), hipMemcpyHostToDevice, up) != hipSuccess) return 1;
+        p->snap_w = w;
+    }
     if (!p->idx.empty() &&
         hipMemcpyAsync(p->d_idx[slot], p->h_idx[slot], p->idx.size() * sizeof(int), hipMemcpyHostToDevice, up) != hipSuccess)
         return 1;
@@ -1259,6 +1281,15 @@ static bool jobs_ensure(FusedPlan *pl, int ntiles)
     return true;
 }
 
+static const bool g_trace = getenv("WAVES_AMD_TRACE") != nullptr;  // diagnostic: the host's decisions of the job protocol, on stderr
+#define WV_TRACE(...)                        \
+    do {                                     \
+        if (g_trace) {                       \
+            fprintf(stderr, "[wv trace] ");  \
+            fprintf(stderr, __VA_ARGS__);    \
+            fprintf(stderr, "\n");           \
+        }                                    \
+    } while (0)
 static unsigned back_status(FusedPlan *pl, int l) { return __atomic_load_n(&pl->back->status[l], __ATOMIC_ACQUIRE); }
 static unsigned back_done(FusedPlan *pl) { return __atomic_load_n(&pl->back->done, __ATOMIC_ACQUIRE); }
 
@@ -1311,6 +1342,7 @@ int fused_retire(FusedPlan *pl)
     if (!pl) return 0;
     if (fused_persist_alive(pl)) {
         pl->seq++;
+        WV_TRACE("retire: EXIT as job %u (done %u)", pl->seq, back_done(pl));
         FusedParams &d = pl->mail->desc[pl->seq & 1u].p;
         d = FusedParams{};
         d.seq = pl->seq;
@@ -1339,6 +1371,7 @@ bool fused_needs_stream(FusedPlan *pl, bool capture, const float *G, int out2_id
 static int jobs_launch(FusedPlan *pl, unsigned first_seq, int ntiles, hipStream_t s)
 {
     const int l = pl->cur_l ^ 1;
+    WV_TRACE("launch record %d first job %u tiles %d", l, first_seq, ntiles);
     if (jobs_join(pl, l) != 0) return 1;  // (the launch before the previous one: long gone)
     // (leftovers of an earlier launch in the go words -- "job n: leave" -- must not be taken for this launch's answer)
     if (hipMemsetAsync(pl->d_ctl->go, 0, sizeof(pl->d_ctl->go), s) != hipSuccess) return 1;
@@ -1410,7 +1443,8 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
         if (fused_retire(pl)) return 1;  // (nothing alive may hold the control block that is about to be replaced)
     }
     if (!jobs_ensure(pl, (int)nt)) {
-        (void)hipGetLastError();
+        fprintf(stderr, "[waves_amd] the resident step kernel is not used by this context: its control blocks could not be allocated (%s)\n",
+                hipGetErrorString(hipGetLastError()));
         pl->resident_capacity = 0;
         return dev ? 3 : -1;
     }
@@ -1504,8 +1538,9 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
         p.cull_t_lo = dev->t_lo;
         p.cull_t_hi = dev->t_hi;
         p.tiles = pl->launch_tiles;
-    } else {
-        pl->launch_tiles = p.tiles;
+    } else if (pl->snap_w >= 0) {
+        pl->launch_tiles = pl->d_snap[pl->snap_w];
+        pl->snap_w = -1;
     }
     // Everything the job reads must be in device memory before the bell rings.  A launch that is already there cannot be
     // made to wait by the stream, so the host waits for the copy stream itself (the uploads are ~100 KB: they are long
@@ -1529,6 +1564,8 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
     pl->seq++;
     desc.p = p;
     __atomic_store_n(&pl->mail->bell, pl->seq, __ATOMIC_RELEASE);
+    WV_TRACE("ring job %u slot %d alive %d dev %d last %d tiles %p steps %p same %d done %u", pl->seq, slot, (int)alive, dev ? 1 : 0, p.last, (const void *)p.tiles,
+             (const void *)p.steps, (int)same, back_done(pl));
     if (!alive) {
         // The new launch starts with this job -- unless the call before it is still pending and was rung just as the previous
         // launch left on its idle limit without taking it (two in flight; found by the soak test: begun with this job, the new
@@ -1546,7 +1583,10 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
         if (rc != 0) {
             pl->seq--;  // (nobody has seen the description)
             __atomic_store_n(&pl->mail->bell, pl->seq, __ATOMIC_RELEASE);
-            if (rc < 0) pl->resident_capacity = 0;  // do not try again
+            if (rc < 0) {  // do not try again
+                fprintf(stderr, "[waves_amd] the resident step kernel is not used by this context: its launch was refused\n");
+                pl->resident_capacity = 0;
+            }
             return rc;
         }
     }
@@ -1594,6 +1634,7 @@ int fused_job_wait(FusedPlan *pl, int slot, hipStream_t s)
         }
         if (complete()) break;
         const unsigned why = back_status(pl, l);
+        WV_TRACE("wait job %u: launch record %d has ended, status %u exit_seq %u done %u", want, l, why, pl->back->exit_seq[l], back_done(pl));
         jobs_reap(pl, l);
         if (why == JOBS_EXIT_ABORT) return 2;
         // it left on its idle limit (or was told to) without having seen this job: the description and the bell are still
@@ -1636,6 +1677,9 @@ void fused_gave_up(FusedPlan *pl, hipStream_t s)
     (void)jobs_join(pl, pl->cur_l ^ 1);
     (void)jobs_join(pl, pl->cur_l);
     (void)hipMemsetAsync(pl->d_abort, 0, sizeof(int), s);
+    // (rare and worth a line: from here on every call of this context pays for a launch per step)
+    fprintf(stderr, "[waves_amd] a resident launch could not make progress (a tile waited in vain for a neighbour: is the device shared with "
+                    "other kernels?); the call was run again by the single-step kernels, which this context keeps using\n");
     pl->use_resident = false;
     for (int k = 0; k < 2; ++k) {
         pl->job_seq[k] = 0;
