@@ -314,3 +314,14 @@ def test_c_host_loop_over_the_abi_alone():
     assert all(o["resident"] == 1 for o in outs), outs
     assert outs[0]["signal_checksum"] == outs[1]["signal_checksum"] == outs[2]["signal_checksum"] != 0
     assert all(o["last_launch_jobs"] == 12 for o in outs), outs   # one launch served the whole timed region
+
+
+def test_fast_host_stress_of_the_job_protocol():
+    """tools/stress/stress_host.cpp: a random mix of calls from a compiled host (calls microseconds apart -- the timing that
+    exposed the launch-order fault of table-less calls), with host pauses around a short idle limit against the same calls
+    undisturbed: same bytes, no give-up, on the resident kernel."""
+    exe = os.path.join(ROOT, "tools", "stress", "stress_host")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "waves.jl_amd", "csrc"), "stress"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    p = subprocess.run([exe, "320", "40", "8", "120"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.strip().endswith("PASS"), p.stdout[-1500:] + p.stderr[-500:]

@@ -1,0 +1,165 @@
+// Stress of the resident launch's job protocol from a FAST host (C++ over the C ABI: calls follow each other within
+// microseconds, which the Python mirror never does).  A random mix of calls -- one action at a time, two in flight, pipelines of
+// three, state(env), synchronize, reset, the state leaving and coming back -- is run twice per seed on a fresh context: once with
+// random host pauses of 0-60 us and a short idle limit of the launch, once undisturbed.  Every trace, observation and the final
+// frames must be the same bytes; a context that loses the resident kernel (give-up) is a failure too.
+//   stress_host [grid 320] [first_seed 0] [n_seeds 10] [ops 200]
+// build: make -C waves.jl_amd/csrc stress
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/waves_amd.h"
+
+static unsigned long long g_rng;
+static unsigned urand32()
+{
+    g_rng = g_rng * 6364136223846793005ull + 1442695040888963407ull;
+    return (unsigned)(g_rng >> 33);
+}
+static float urand() { return (float)((urand32() >> 7) * (1.0 / 16777216.0)); }
+static void spin(double us)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < us) {}
+}
+
+#define CK(call)                                                                                 \
+    do {                                                                                         \
+        const int rc_ = (call);                                                                  \
+        if (rc_ != 0) {                                                                          \
+            fprintf(stderr, "%s -> %d: %s\n", #call, rc_, wv_last_error(ctx));                   \
+            return false;                                                                        \
+        }                                                                                        \
+    } while (0)
+
+struct Result {
+    std::vector<float> out;
+    int gave_up = 0, resident = 0;
+};
+
+static bool run(int n, unsigned long long seed, int ops, bool jitter, Result &res)
+{
+    // the pattern and the actions come from `seed` alone; the pauses from a generator of their own
+    g_rng = seed * 2654435761ull + 12345ull;
+    unsigned long long jit = seed ^ 0xabcdef12345ull;
+    auto jrand = [&]() { jit = jit * 6364136223846793005ull + 1442695040888963407ull; return (double)(jit >> 40) / 16777216.0; };
+    const int steps = 30, M = 19;
+    const float dt = 1e-5f;
+    wv_ctx *ctx = nullptr;
+    std::vector<float> x(n);
+    for (int i = 0; i < n; ++i) x[i] = (float)(-15.0 + 30.0 * i / (n - 1));
+    wv_config cfg{n, n, 1531.0f, dt, 2.0f, 20000.0f, 0, WV_IMPL_AUTO};
+    CK(wv_create(&cfg, x.data(), x.data(), &ctx));
+    const float mu[2] = {-10.0f, 2.5f}, sigma[1] = {0.3f}, amp[1] = {1.0f};
+    CK(wv_set_gaussian_source(ctx, 1, mu, sigma, amp, 1000.0f));
+    CK(wv_reset(ctx));
+    std::vector<float> pos(2 * M), c(M), r0(M), r1(M);
+    const double ring_r[3] = {3.5, 4.75, 6.0}, ring_rot[3] = {0.0, M_PI / 6.0, 0.0};
+    for (int k = 0; k < 3; ++k)
+        for (int j = 0; j < 6; ++j) {
+            const double a = j * 2.0 * M_PI / 6.0 + ring_rot[k];
+            pos[6 * k + j] = (float)(ring_r[k] * cos(a) + 5.0);
+            pos[M + 6 * k + j] = (float)(ring_r[k] * sin(a));
+            c[6 * k + j] = 3.0f * 344.0f;
+            r0[6 * k + j] = 0.2f + 0.8f * urand();
+        }
+    pos[18] = 5.0f, pos[M + 18] = 0.0f, c[18] = 3.0f * 344.0f, r0[18] = 2.0f;
+    const float scale = 250.0f * dt * (float)steps;
+    std::vector<float> tspan(steps + 1), sig(3 * (steps + 1)), obs(128 * 128 * 4), state((size_t)12 * n * n);
+    int step0 = 0, pending = 0;
+    auto pause = [&]() { if (jitter) spin(60.0 * jrand()); };
+    auto begin = [&]() -> bool {
+        for (int j = 0; j < 18; ++j) r1[j] = fminf(fmaxf(r0[j] + scale * (2.0f * urand() - 1.0f), 0.2f), 1.0f);
+        r1[18] = r0[18];
+        for (int s = 0; s <= steps; ++s) tspan[s] = (float)((double)(step0 + s) * (double)dt);
+        CK(wv_set_design(ctx, M, pos.data(), r0.data(), c.data(), pos.data(), r1.data(), c.data(), tspan[0], tspan[steps]));
+        CK(wv_integrate_begin(ctx, tspan.data(), steps, 1, 1, 0));
+        r0.swap(r1);
+        step0 += steps;
+        ++pending;
+        return true;
+    };
+    auto end = [&]() -> bool {
+        CK(wv_integrate_end(ctx, sig.data(), nullptr, nullptr));
+        res.out.insert(res.out.end(), sig.begin(), sig.end());
+        wv_timing t{};
+        CK(wv_get_timing(ctx, &t));
+        res.gave_up += t.gave_up;
+        res.resident = t.resident;
+        --pending;
+        return true;
+    };
+    for (int op = 0; op < ops; ++op) {
+        const unsigned kind = urand32() % 16;
+        pause();
+        if (kind < 5) {
+            if (!begin()) return false;
+            pause();
+            if (!end()) return false;
+        } else if (kind < 9) {
+            if (!begin() || !begin()) return false;
+            pause();
+            if (!end()) return false;
+            pause();
+            if (!end()) return false;
+        } else if (kind < 11) {  // a pipeline: never fewer than one call in flight for a while
+            if (!begin()) return false;
+            for (int k = 0; k < 4; ++k) {
+                if (!begin()) return false;
+                pause();
+                if (!end()) return false;
+            }
+            if (!end()) return false;
+        } else if (kind < 13) {
+            CK(wv_observation(ctx, 128, 128, obs.data()));
+            res.out.insert(res.out.end(), obs.begin(), obs.begin() + 4096);
+            res.out.insert(res.out.end(), obs.end() - 4096, obs.end());
+        } else if (kind == 13) {
+            CK(wv_synchronize(ctx));
+        } else if (kind == 14) {
+            CK(wv_reset(ctx));
+        } else {
+            CK(wv_get_state(ctx, state.data()));
+            res.out.push_back(state[(size_t)n * (n / 2) + n / 3]);
+            CK(wv_set_state(ctx, state.data()));
+        }
+    }
+    CK(wv_get_state(ctx, state.data()));
+    res.out.insert(res.out.end(), state.begin(), state.begin() + (size_t)n * n);
+    CK(wv_destroy(ctx));
+    return true;
+}
+
+int main(int argc, char **argv)
+{
+    const int n = argc > 1 ? atoi(argv[1]) : 320;
+    const int first = argc > 2 ? atoi(argv[2]) : 0, nseeds = argc > 3 ? atoi(argv[3]) : 10, ops = argc > 4 ? atoi(argv[4]) : 200;
+    const int idles[6] = {10, 20, 35, 50, 80, 1000};
+    int bad = 0;
+    for (int s = first; s < first + nseeds; ++s) {
+        char buf[32];
+        snprintf(buf, sizeof buf, "%d", idles[s % 6]);
+        setenv("WAVES_AMD_IDLE_US", buf, 1);
+        Result a, b;
+        const bool oka = run(n, (unsigned long long)s, ops, true, a);
+        unsetenv("WAVES_AMD_IDLE_US");
+        const bool okb = run(n, (unsigned long long)s, ops, false, b);
+        const bool same = oka && okb && a.out.size() == b.out.size() && memcmp(a.out.data(), b.out.data(), a.out.size() * sizeof(float)) == 0;
+        const bool ok = same && a.gave_up == 0 && b.gave_up == 0 && a.resident && b.resident;
+        size_t firstdiff = 0;
+        if (oka && okb && !same)
+            for (; firstdiff < a.out.size() && firstdiff < b.out.size(); ++firstdiff)
+                if (memcmp(&a.out[firstdiff], &b.out[firstdiff], 4) != 0) break;
+        printf("seed %d idle %s us: %zu values, give-ups %d/%d, resident %d/%d: %s", s, buf, a.out.size(), a.gave_up, b.gave_up, a.resident, b.resident,
+               ok ? "same bytes\n" : "FAILED");
+        if (!ok) printf(" (first difference at value %zu)\n", firstdiff);
+        fflush(stdout);
+        bad += ok ? 0 : 1;
+    }
+    printf(bad ? "FAILED\n" : "PASS\n");
+    return bad ? 1 : 0;
+}
