@@ -47,7 +47,8 @@ static bool run(int n, unsigned long long seed, int ops, bool jitter, Result &re
     g_rng = seed * 2654435761ull + 12345ull;
     unsigned long long jit = seed ^ 0xabcdef12345ull;
     auto jrand = [&]() { jit = jit * 6364136223846793005ull + 1442695040888963407ull; return (double)(jit >> 40) / 16777216.0; };
-    const int steps = 30, M = 19;
+    const int max_steps = 40, M = 19;
+    int steps = 30;
     const float dt = 1e-5f;
     wv_ctx *ctx = nullptr;
     std::vector<float> x(n);
@@ -68,24 +69,44 @@ static bool run(int n, unsigned long long seed, int ops, bool jitter, Result &re
             r0[6 * k + j] = 0.2f + 0.8f * urand();
         }
     pos[18] = 5.0f, pos[M + 18] = 0.0f, c[18] = 3.0f * 344.0f, r0[18] = 2.0f;
-    const float scale = 250.0f * dt * (float)steps;
-    std::vector<float> tspan(steps + 1), sig(3 * (steps + 1)), obs(128 * 128 * 4), state((size_t)12 * n * n);
-    int step0 = 0, pending = 0;
+    const float scale = 250.0f * dt * 30.0f;
+    std::vector<float> tspan(max_steps + 1), sig(3 * (max_steps + 1)), obs(128 * 128 * 4), state((size_t)12 * n * n);
+    std::vector<float> ut((size_t)(max_steps + 1) * n * n), ui((size_t)(max_steps + 1) * n * n);
+    int step0 = 0, pending = 0, fields = 0;
+    std::vector<int> pend_steps, pend_fields;
     auto pause = [&]() { if (jitter) spin(60.0 * jrand()); };
     auto begin = [&]() -> bool {
         for (int j = 0; j < 18; ++j) r1[j] = fminf(fmaxf(r0[j] + scale * (2.0f * urand() - 1.0f), 0.2f), 1.0f);
         r1[18] = r0[18];
         for (int s = 0; s <= steps; ++s) tspan[s] = (float)((double)(step0 + s) * (double)dt);
         CK(wv_set_design(ctx, M, pos.data(), r0.data(), c.data(), pos.data(), r1.data(), c.data(), tspan[0], tspan[steps]));
-        CK(wv_integrate_begin(ctx, tspan.data(), steps, 1, 1, 0));
+        CK(wv_integrate_begin(ctx, tspan.data(), steps, 1, 1, fields));
         r0.swap(r1);
         step0 += steps;
         ++pending;
+        pend_steps.push_back(steps);
+        pend_fields.push_back(fields);
         return true;
     };
     auto end = [&]() -> bool {
-        CK(wv_integrate_end(ctx, sig.data(), nullptr, nullptr));
-        res.out.insert(res.out.end(), sig.begin(), sig.end());
+        const int ns = pend_steps.front(), wf = pend_fields.front();
+        pend_steps.erase(pend_steps.begin());
+        pend_fields.erase(pend_fields.begin());
+        if (wf == 2) {
+            const float *vt = nullptr, *vi = nullptr;
+            int planes = 0;
+            CK(wv_integrate_end_view(ctx, sig.data(), &vt, &vi, &planes));
+            res.out.push_back((float)planes);
+            res.out.insert(res.out.end(), vt + (size_t)(planes - 1) * n * n, vt + (size_t)planes * n * n);
+            res.out.insert(res.out.end(), vi + (size_t)(planes / 2) * n * n, vi + (size_t)(planes / 2) * n * n + n);
+        } else if (wf == 1) {
+            CK(wv_integrate_end(ctx, sig.data(), ut.data(), ui.data()));
+            res.out.insert(res.out.end(), ut.begin() + (size_t)ns * n * n, ut.begin() + (size_t)(ns + 1) * n * n);
+            res.out.insert(res.out.end(), ui.begin() + (size_t)(ns / 2) * n * n, ui.begin() + (size_t)(ns / 2) * n * n + n);
+        } else {
+            CK(wv_integrate_end(ctx, sig.data(), nullptr, nullptr));
+        }
+        res.out.insert(res.out.end(), sig.begin(), sig.begin() + 3 * (ns + 1));
         wv_timing t{};
         CK(wv_get_timing(ctx, &t));
         res.gave_up += t.gave_up;
@@ -94,7 +115,9 @@ static bool run(int n, unsigned long long seed, int ops, bool jitter, Result &re
         return true;
     };
     for (int op = 0; op < ops; ++op) {
-        const unsigned kind = urand32() % 16;
+        const unsigned kind = urand32() % 20;
+        steps = 20 + 10 * (int)(urand32() % 3);   // 20 (the first frame is the initial state: needs the stream), 30, 40
+        fields = 0;
         pause();
         if (kind < 5) {
             if (!begin()) return false;
@@ -122,10 +145,32 @@ static bool run(int n, unsigned long long seed, int ops, bool jitter, Result &re
             CK(wv_synchronize(ctx));
         } else if (kind == 14) {
             CK(wv_reset(ctx));
-        } else {
+        } else if (kind == 15) {
             CK(wv_get_state(ctx, state.data()));
             res.out.push_back(state[(size_t)n * (n / 2) + n / 3]);
             CK(wv_set_state(ctx, state.data()));
+        } else if (kind == 16) {  // an action that returns its trajectories
+            fields = 1;
+            if (!begin()) return false;
+            pause();
+            if (!end()) return false;
+        } else if (kind == 17) {  // streamed trajectories, two such calls in flight
+            fields = 2;
+            if (!begin() || !begin()) return false;
+            pause();
+            if (!end()) return false;
+            pause();
+            if (!end()) return false;
+        } else if (kind == 18) {  // the right-hand side between two actions
+            CK(wv_get_state(ctx, state.data()));
+            std::vector<float> k12((size_t)12 * n * n);
+            CK(wv_rhs(ctx, state.data(), (float)(step0 * (double)dt), k12.data()));
+            res.out.insert(res.out.end(), k12.begin() + (size_t)n * (n / 2), k12.begin() + (size_t)n * (n / 2) + n);
+        } else {                  // profiling mode for one action
+            CK(wv_set_profiling(ctx, 1));
+            if (!begin()) return false;
+            if (!end()) return false;
+            CK(wv_set_profiling(ctx, 0));
         }
     }
     CK(wv_get_state(ctx, state.data()));
