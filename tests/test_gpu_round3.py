@@ -190,7 +190,7 @@ def test_observation_of_the_job_follows_every_change_of_the_state():
     """The observation a job leaves in pinned memory is only handed out while it IS state(env): after reset, set_state, a new
     source, another resolution, or with two calls pending, wv_observation goes back to the frames."""
     gc.collect()
-    env, pol = _env(300, 30, 8, 71)
+    env, pol = _env(300, 30, 16, 71)
     ref_env, ref_pol = None, None
     env.state()
     env(pol(env))
@@ -216,6 +216,18 @@ def test_observation_of_the_job_follows_every_change_of_the_state():
     os.environ["WAVES_AMD_OBS_IN_JOB"] = "0"
     try:
         assert np.array_equal(np.array(env.state().wave), e)
+    finally:
+        del os.environ["WAVES_AMD_OBS_IN_JOB"]
+    env(pol(env))                                         # (a job that leaves its observation in this slot's buffer ...)
+    env(pol(env))
+    env.ctx.set_profiling(True)                           # ... then a call of a kind that produces none in the same slot
+    env(pol(env))
+    env(pol(env))
+    env.ctx.set_profiling(False)
+    f = np.array(env.state().wave)                        # must not be the older job's (found by tools/stress: resident vs single-step)
+    os.environ["WAVES_AMD_OBS_IN_JOB"] = "0"
+    try:
+        assert np.array_equal(np.array(env.ctx.observation(*env.resolution)), f)
     finally:
         del os.environ["WAVES_AMD_OBS_IN_JOB"]
     env.reset()
@@ -324,4 +336,8 @@ def test_fast_host_stress_of_the_job_protocol():
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "waves.jl_amd", "csrc"), "stress"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     p = subprocess.run([exe, "320", "40", "8", "120"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.strip().endswith("PASS"), p.stdout[-1500:] + p.stderr[-500:]
+    # ... and against the SINGLE-STEP kernels on the undisturbed side: every trace, observation, trajectory plane and
+    # right-hand side the same bytes whichever kernel integrated
+    p = subprocess.run([exe, "320", "60", "6", "100", "1", "1"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and p.stdout.strip().endswith("PASS"), p.stdout[-1500:] + p.stderr[-500:]

@@ -3,7 +3,7 @@
 // three, state(env), synchronize, reset, the state leaving and coming back -- is run twice per seed on a fresh context: once with
 // random host pauses of 0-60 us and a short idle limit of the launch, once undisturbed.  Every trace, observation and the final
 // frames must be the same bytes; a context that loses the resident kernel (give-up) is a failure too.
-//   stress_host [grid 320] [first_seed 0] [n_seeds 10] [ops 200]
+//   stress_host [grid 320] [first_seed 0] [n_seeds 10] [ops 200] [need_resident 1] [second run on the single-step kernels 0]
 // build: make -C waves.jl_amd/csrc stress
 #include <chrono>
 #include <cmath>
@@ -38,6 +38,8 @@ static void spin(double us)
 
 struct Result {
     std::vector<float> out;
+    std::vector<size_t> op_at;   // out.size() at the start of every operation
+    std::vector<int> op_kind, op_steps;
     int gave_up = 0, resident = 0;
 };
 
@@ -118,6 +120,9 @@ static bool run(int n, unsigned long long seed, int ops, bool jitter, Result &re
         const unsigned kind = urand32() % 20;
         steps = 20 + 10 * (int)(urand32() % 3);   // 20 (the first frame is the initial state: needs the stream), 30, 40
         fields = 0;
+        res.op_at.push_back(res.out.size());
+        res.op_kind.push_back((int)kind);
+        res.op_steps.push_back(steps);
         pause();
         if (kind < 5) {
             if (!begin()) return false;
@@ -183,6 +188,8 @@ int main(int argc, char **argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 320;
     const int first = argc > 2 ? atoi(argv[2]) : 0, nseeds = argc > 3 ? atoi(argv[3]) : 10, ops = argc > 4 ? atoi(argv[4]) : 200;
+    const bool need_resident = !(argc > 5 && atoi(argv[5]) == 0);  // 0: grids beyond the resident kernel (single-step kernels)
+    const bool cross = argc > 6 && atoi(argv[6]) != 0;             // 1: the undisturbed run on the single-step kernels (resident vs single-step)
     const int idles[6] = {10, 20, 35, 50, 80, 1000};
     int bad = 0;
     for (int s = first; s < first + nseeds; ++s) {
@@ -192,16 +199,25 @@ int main(int argc, char **argv)
         Result a, b;
         const bool oka = run(n, (unsigned long long)s, ops, true, a);
         unsetenv("WAVES_AMD_IDLE_US");
+        if (cross) setenv("WAVES_AMD_FUSED_RESIDENT", "0", 1);
         const bool okb = run(n, (unsigned long long)s, ops, false, b);
+        if (cross) unsetenv("WAVES_AMD_FUSED_RESIDENT");
         const bool same = oka && okb && a.out.size() == b.out.size() && memcmp(a.out.data(), b.out.data(), a.out.size() * sizeof(float)) == 0;
-        const bool ok = same && a.gave_up == 0 && b.gave_up == 0 && a.resident && b.resident;
+        const bool ok = same && a.gave_up == 0 && b.gave_up == 0 && (!need_resident || (a.resident && (cross || b.resident)));
         size_t firstdiff = 0;
         if (oka && okb && !same)
             for (; firstdiff < a.out.size() && firstdiff < b.out.size(); ++firstdiff)
                 if (memcmp(&a.out[firstdiff], &b.out[firstdiff], 4) != 0) break;
         printf("seed %d idle %s us: %zu values, give-ups %d/%d, resident %d/%d: %s", s, buf, a.out.size(), a.gave_up, b.gave_up, a.resident, b.resident,
                ok ? "same bytes\n" : "FAILED");
-        if (!ok) printf(" (first difference at value %zu)\n", firstdiff);
+        if (!ok) {
+            size_t k = 0;
+            while (k + 1 < a.op_at.size() && a.op_at[k + 1] <= firstdiff) ++k;
+            printf(" (first difference at value %zu: operation %zu of kind %d with %d steps, offset %zu in it; kinds before: %d %d %d; %g vs %g)\n", firstdiff, k,
+                   a.op_kind.empty() ? -1 : a.op_kind[k], a.op_steps.empty() ? 0 : a.op_steps[k], a.op_at.empty() ? 0 : firstdiff - a.op_at[k],
+                   k > 0 ? a.op_kind[k - 1] : -1, k > 1 ? a.op_kind[k - 2] : -1, k > 2 ? a.op_kind[k - 3] : -1,
+                   firstdiff < a.out.size() ? a.out[firstdiff] : 0.0f, firstdiff < b.out.size() ? b.out[firstdiff] : 0.0f);
+        }
         fflush(stdout);
         bad += ok ? 0 : 1;
     }

@@ -934,6 +934,7 @@ int wv_integrate_begin(wv_ctx *c, const float *tspan, int nsteps, int capture, i
     const int si = c->next_slot;
     wv_ctx::Slot &q = c->slot[si];
     c->obs_slot = -1;  // (the frames are about to change)
+    q.obs_rx = q.obs_ry = 0;  // (set again below when this call's job produces the observation: not by every kind of call)
     // The copy stream is created when first needed, and only by a context that has its device to itself: HIP multiplexes
     // the streams of a process over a few hardware queues, and with several environments per GPU (one stream each) extra
     // streams make kernels of different environments queue behind each other (8 envs: 45 -> 35 Gcell-updates/s).
