@@ -117,7 +117,7 @@ static bool run(int n, unsigned long long seed, int ops, bool jitter, Result &re
         return true;
     };
     for (int op = 0; op < ops; ++op) {
-        const unsigned kind = urand32() % 20;
+        const unsigned kind = urand32() % 28;
         steps = 20 + 10 * (int)(urand32() % 3);   // 20 (the first frame is the initial state: needs the stream), 30, 40
         fields = 0;
         res.op_at.push_back(res.out.size());
@@ -171,11 +171,87 @@ static bool run(int n, unsigned long long seed, int ops, bool jitter, Result &re
             std::vector<float> k12((size_t)12 * n * n);
             CK(wv_rhs(ctx, state.data(), (float)(step0 * (double)dt), k12.data()));
             res.out.insert(res.out.end(), k12.begin() + (size_t)n * (n / 2), k12.begin() + (size_t)n * (n / 2) + n);
-        } else {                  // profiling mode for one action
+        } else if (kind == 19) {  // profiling mode for one action
             CK(wv_set_profiling(ctx, 1));
             if (!begin()) return false;
             if (!end()) return false;
             CK(wv_set_profiling(ctx, 0));
+        } else if (kind == 20 || kind == 21) {  // three actions as ONE call (kind 21: every action's frames kept, observed afterwards)
+            const int na = 3, sps = kind == 21 && steps == 20 ? 30 : steps;
+            std::vector<float> dsg((size_t)(na + 1) * M * 4), tt(2 * na), ts((size_t)na * (sps + 1)), sg((size_t)3 * (na * sps + 1));
+            for (int a = 0; a <= na; ++a) {
+                if (a > 0) {
+                    for (int j = 0; j < 18; ++j) r1[j] = fminf(fmaxf(r0[j] + scale * (2.0f * urand() - 1.0f), 0.2f), 1.0f);
+                    r1[18] = r0[18];
+                    r0.swap(r1);
+                }
+                for (int m = 0; m < M; ++m) {
+                    float *d = &dsg[((size_t)a * M + m) * 4];
+                    d[0] = pos[m], d[1] = pos[M + m], d[2] = r0[m], d[3] = c[m];
+                }
+            }
+            for (int a = 0; a < na; ++a) {
+                for (int q = 0; q <= sps; ++q) ts[(size_t)a * (sps + 1) + q] = (float)((double)(step0 + a * sps + q) * (double)dt);
+                tt[2 * a] = ts[(size_t)a * (sps + 1)], tt[2 * a + 1] = ts[(size_t)a * (sps + 1) + sps];
+            }
+            CK(wv_set_design_sequence(ctx, na, sps, M, dsg.data(), tt.data()));
+            CK(wv_integrate_begin(ctx, ts.data(), na * sps, kind == 21 ? 2 : 1, 1, 0));
+            pause();
+            CK(wv_integrate_end(ctx, sg.data(), nullptr, nullptr));
+            res.out.insert(res.out.end(), sg.begin(), sg.end());
+            step0 += na * sps;
+            if (kind == 21)
+                for (int a = 0; a < na; ++a) {
+                    CK(wv_observation_action(ctx, a, 128, 128, obs.data()));
+                    res.out.insert(res.out.end(), obs.begin() + 8192, obs.begin() + 8192 + 2048);
+                }
+        } else if (kind == 22) {  // the source moves
+            const float mu2[2] = {-10.0f, -8.0f + 16.0f * urand()};
+            CK(wv_set_gaussian_source(ctx, 1, mu2, sigma, amp, 1000.0f));
+            if (!begin()) return false;
+            if (!end()) return false;
+        } else if (kind == 23) {  // the coefficient fields of the current design / source
+            std::vector<float> f((size_t)n * n);
+            CK(wv_speed_field(ctx, (float)(step0 * (double)dt), f.data()));
+            res.out.insert(res.out.end(), f.begin() + (size_t)n * (n / 2), f.begin() + (size_t)n * (n / 2) + n);
+            CK(wv_source_field(ctx, (float)(step0 * (double)dt), f.data()));
+            res.out.insert(res.out.end(), f.begin() + (size_t)n * (n / 3), f.begin() + (size_t)n * (n / 3) + n);
+        } else if (kind == 24) {  // env.wave leaves and comes back
+            std::vector<float> wv((size_t)12 * n * n * 3);
+            CK(wv_get_frames(ctx, wv.data()));
+            res.out.insert(res.out.end(), wv.begin() + (size_t)n * (n / 2), wv.begin() + (size_t)n * (n / 2) + n);
+            CK(wv_set_frames(ctx, wv.data()));
+        } else if (kind == 25) {  // somebody holds the raw pointer of env.wave over an action
+            void *dp = nullptr;
+            size_t bytes = 0;
+            CK(wv_device_frames(ctx, &dp, &bytes));
+            if (!begin()) return false;
+            if (!end()) return false;
+            CK(wv_observation(ctx, 128, 128, obs.data()));
+            res.out.insert(res.out.end(), obs.begin(), obs.begin() + 2048);
+            CK(wv_release_device_frames(ctx));
+        } else if (kind == 26) {  // strided trajectories
+            CK(wv_set_trajectory_stride(ctx, 5));
+            fields = 1;
+            if (!begin()) return false;
+            {
+                const int ns = pend_steps.front();
+                pend_steps.clear();
+                pend_fields.clear();
+                CK(wv_integrate_end(ctx, sig.data(), ut.data(), ui.data()));
+                --pending;
+                const int planes = ns / 5 + 1;
+                res.out.insert(res.out.end(), ut.begin() + (size_t)(planes - 1) * n * n, ut.begin() + (size_t)planes * n * n);
+                res.out.insert(res.out.end(), sig.begin(), sig.begin() + 3 * (ns + 1));
+            }
+            CK(wv_set_trajectory_stride(ctx, 1));
+        } else {                  // an action without a design (NoDesign: C(t) = c0), then the design again
+            for (int s2 = 0; s2 <= steps; ++s2) tspan[s2] = (float)((double)(step0 + s2) * (double)dt);
+            CK(wv_set_design(ctx, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tspan[0], tspan[steps]));
+            CK(wv_integrate_begin(ctx, tspan.data(), steps, 1, 1, 0));
+            CK(wv_integrate_end(ctx, sig.data(), nullptr, nullptr));
+            res.out.insert(res.out.end(), sig.begin(), sig.begin() + 3 * (steps + 1));
+            step0 += steps;
         }
     }
     CK(wv_get_state(ctx, state.data()));
