@@ -497,7 +497,9 @@ def main():
     assert len(ds.low.config) == 18 and len(ds.low.core) == 1  # every rank holds rank 0's triple-ring block
 
     if world > 1:
-        wd.gather_signals(np.zeros(2, np.float32))  # warm the communicator up outside the timed region
+        # warm the communicator up outside the timed region, with a buffer of the very shape the timed gather will carry
+        shape = (args.steps, STEPS_PER_ACTION + 1, 3) if E == 1 else (args.steps, E, STEPS_PER_ACTION + 1, 3)
+        wd.gather_signals(np.zeros(shape, np.float32))
     # A full collection of the interpreter's cyclic GC takes 30-50 ms once torch is imported (millions of objects) and
     # would land in the middle of a 1 ms action every few hundred allocations: park everything allocated so far in the
     # permanent generation, as long-running Python services do.  In FRONT of the warm-up: the collection leaves the host's
