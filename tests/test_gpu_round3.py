@@ -341,3 +341,33 @@ def test_fast_host_stress_of_the_job_protocol():
     # right-hand side the same bytes whichever kernel integrated
     p = subprocess.run([exe, "320", "60", "6", "100", "1", "1"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and p.stdout.strip().endswith("PASS"), p.stdout[-1500:] + p.stderr[-500:]
+
+
+def test_idle_limit_adapts_to_the_caller():
+    """A launch that waits for the next call occupies nearly all block slots: when the caller keeps finding it gone (it works
+    on the GPU itself between actions, or is simply slow), the limit shrinks -- and grows back as soon as calls find the launch
+    waiting again.  Seen from outside through the number of calls the last launch served."""
+    gc.collect()
+    env, pol = _env(300, 30, 64, 90)
+    for _ in range(4):
+        env(pol(env))
+    env.ctx.synchronize()
+    assert env.ctx.timing()["launch_jobs"] == 4          # the quick loop: one launch
+    for _ in range(5):                                    # long pauses: 1000 -> 250 -> 62 -> 50 us
+        env(pol(env))
+        time.sleep(0.004)
+    env.ctx.synchronize()
+    env(pol(env))
+    _spin(300)                                            # 0.3 ms: within the default limit, far beyond the shrunken one
+    env(pol(env))
+    env.ctx.synchronize()
+    assert env.ctx.timing()["launch_jobs"] == 1          # the launch had left
+    for _ in range(12):                                   # a quick loop again: the limit recovers (probe, then growth) ...
+        env(pol(env))
+    env.ctx.synchronize()
+    env(pol(env))
+    _spin(300)
+    env(pol(env))
+    env.ctx.synchronize()
+    assert env.ctx.timing()["launch_jobs"] == 2          # ... and a 0.3 ms pause is waited out again
+    env.ctx.close()

@@ -749,7 +749,18 @@ struct FusedPlan {
     // the action-outliving launch (fused_body.h, "jobs")
     bool persist = true;          // WAVES_AMD_PERSIST=0: every resident launch ends with its job
     bool allow_persist = true;    // set per call by the owner (profiling, caller-owned streams, shared devices: false)
-    unsigned idle_us = 1000;      // WAVES_AMD_IDLE_US: the launch leaves after this long without a new job
+    unsigned idle_us = 1000;      // WAVES_AMD_IDLE_US: the launch leaves after this long without a new job (at most: see idle_cur)
+    // How long the NEXT launch waits: a launch that waits occupies nearly every block slot of the device, so whatever else the
+    // caller runs on it between two actions (a policy network, a planner: scripts/mpc.jl) crawls until the launch leaves.  The
+    // host sees which it was: a call that finds the launch gone says the waiting was wasted -- a quarter as long next time (not
+    // below 50 us, where a limit just above the last gap is tried now and then: a merely slow host gets its launch back that
+    // way); one that finds it waiting lets the limit grow back, half as much again per call (never above idle_us).  WAVES_AMD_IDLE_ADAPT=0: always idle_us.  (700^2, a small torch MLP on state(env) between the actions: 2.24 ms
+    // per action with a fixed 1 ms, 1.39 ms adaptive, tools/exp_gpu_policy.py.)
+    unsigned idle_cur = 1000;
+    bool idle_adapt = true, idle_probe = false;
+    unsigned idle_backoff = 1, idle_exits = 0;
+    std::chrono::steady_clock::time_point t_last_done{};  // when the host saw the newest job complete
+    bool have_last_done = false;
     JobMail *mail = nullptr;      // pinned host memory
     JobBack *back = nullptr;      // pinned host memory
     JobCtl *d_ctl = nullptr;
@@ -818,6 +829,8 @@ FusedPlan *fused_create(const Grid &g, const float *x, const float *y, const flo
     if (const char *e = getenv("WAVES_AMD_PERSIST")) p->persist = atoi(e) != 0;
     if (const char *e = getenv("WAVES_AMD_IDLE_US")) p->idle_us = (unsigned)std::max(0, atoi(e));
     if (p->idle_us == 0) p->persist = false;
+    p->idle_cur = p->idle_us;
+    if (const char *e = getenv("WAVES_AMD_IDLE_ADAPT")) p->idle_adapt = atoi(e) != 0;
     if (hipMalloc((void **)&p->d_flag, sizeof(int)) != hipSuccess || hipMalloc((void **)&p->d_abort, 4 * sizeof(int)) != hipSuccess ||
         hipHostMalloc((void **)&p->h_abort, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&p->up_ev[0], hipEventDisableTiming) != hipSuccess ||
@@ -1381,7 +1394,7 @@ static int jobs_launch(FusedPlan *pl, unsigned first_seq, int ntiles, hipStream_
     a.back = pl->back;
     a.ctl = pl->d_ctl;
     a.first_seq = first_seq;
-    const unsigned long long ticks = (unsigned long long)pl->idle_us * 100ull;
+    const unsigned long long ticks = (unsigned long long)(pl->idle_adapt ? pl->idle_cur : pl->idle_us) * 100ull;
     a.idle_ticks = (unsigned)std::min<unsigned long long>(ticks, 0x7fffffffull);
     a.ntiles = ntiles;
     a.launch = l;
@@ -1424,6 +1437,34 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
     const size_t nt = pl->hp.tiles.size();
     if (nsteps < 2 || (int)nt > resident_capacity(pl) || (int)nt > JOB_MAX_TILES) return dev ? 3 : -1;
     bool alive = fused_persist_alive(pl);
+    if (pl->idle_adapt && pl->have_last_done) {  // (see FusedPlan::idle_cur)
+        const double gap = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - pl->t_last_done).count();
+        const unsigned lo = std::min(50u, pl->idle_us);
+        if (alive) {  // found waiting: the limit may grow back, half as much again per call
+            pl->idle_cur = std::min(pl->idle_us, pl->idle_cur + pl->idle_cur / 2u + 1u);
+            pl->idle_probe = false;
+            pl->idle_backoff = 1;
+            pl->idle_exits = 0;
+        } else if (pl->L[pl->cur_l].alive && back_status(pl, pl->cur_l) == JOBS_EXIT_IDLE) {
+            // It waited out its limit in vain.  How long the caller WOULD have taken cannot be told from the gap: work of the
+            // caller's on this device only gets going once the launch has left, so the gap is "limit + that work" -- or the
+            // host was simply slow (then a limit above the gap would have caught the call).  So: shrink; and once at the floor,
+            // try now and then whether a limit above the last gap catches the next call (a probe that fails is dropped at once,
+            // and the next one comes after twice as many exits).
+            if (pl->idle_probe) {
+                pl->idle_probe = false;
+                pl->idle_cur = lo;
+                pl->idle_backoff = std::min(64u, pl->idle_backoff * 2u);
+                pl->idle_exits = 0;
+            } else if (pl->idle_cur > lo) {
+                pl->idle_cur = std::max(lo, pl->idle_cur / 4u);
+            } else if (++pl->idle_exits >= pl->idle_backoff && 2.0 * gap < (double)pl->idle_us) {
+                pl->idle_cur = std::max(lo, (unsigned)(2.0 * gap));
+                pl->idle_probe = true;
+            }
+        }
+        pl->have_last_done = false;  // (one verdict per completed job)
+    }
     if (!alive && !pl->granules_checked) {  // (before this plan's first resident launch; the stream is free then)
         pl->granules_checked = true;
         if (!granules_ok(s)) {
@@ -1663,6 +1704,8 @@ int fused_job_wait(FusedPlan *pl, int slot, hipStream_t s)
                 (double)(long long)(t1 - t0) * 0.01);
     }
     pl->last_job_ms = ms;
+    pl->t_last_done = std::chrono::steady_clock::now();
+    pl->have_last_done = true;
     if (pl->job_ms.size() < (size_t)1 << 16) pl->job_ms.push_back(ms);
     // a launch that ended with this job: take its stop event (it is microseconds away) so that its duration is known
     if (!pl->job_keep[slot] && pl->L[l].alive && !pl->L[l].stays && jobs_join(pl, l) != 0) return 1;
