@@ -480,7 +480,7 @@ def main():
     ds = wd.broadcast_design_space(ds, src=0)
     dim = w.TwoDim(15.0, ngrid)
     E = max(1, args.envs_per_gpu)
-    total_actions = args.warmup + args.steps
+    total_actions = args.warmup + 11 * args.steps   # (+ the ten times longer window behind the timed one: roofline "sustained")
     envs, pols = [], []
     for e in range(E):
         if args.stub_env:
@@ -654,6 +654,19 @@ def main():
             "signal_checksum": float(np.sum(all_sig[0][-1])),
         }
         out["ranks_gathered"] = len(all_sig)
+        if world == 1 and args.side_configs and E == 1 and not args.stub_env:
+            # The same loop over a window ten times as long (never `value`: the contract times exactly --steps actions): what
+            # the headline is worth beyond a 19-ms window -- the launch's ramp and the region's ends weigh a tenth.
+            n_long = 10 * args.steps
+            sync_device()
+            t0l = time.perf_counter()
+            timed_rollout(env, policy, n_long, args.in_flight)
+            env.ctx.synchronize()
+            sync_device()
+            dtl = time.perf_counter() - t0l
+            out["sustained"] = {"actions": n_long, "ms_per_step": round(dtl / n_long * 1e3, 4),
+                                "value": round(n_long * cells * STEPS_PER_ACTION / dtl / 1e6, 2), "unit": "Mcell-updates/s",
+                                "whole_job_frac": round(B_ALG * n_long * cells * STEPS_PER_ACTION / dtl / (HBM_PEAK_GBS * 1e9), 4)}
         if world == 1 and args.side_configs and ngrid == N_GRID and E == 1 and not args.stub_env:
             for en in envs:  # (a context takes the resident path only when it has the device to itself)
                 en.ctx.close()
