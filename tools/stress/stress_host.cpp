@@ -117,7 +117,7 @@ static bool run(int n, unsigned long long seed, int ops, bool jitter, Result &re
         return true;
     };
     for (int op = 0; op < ops; ++op) {
-        const unsigned kind = urand32() % 28;
+        const unsigned kind = urand32() % 30;
         steps = 20 + 10 * (int)(urand32() % 3);   // 20 (the first frame is the initial state: needs the stream), 30, 40
         fields = 0;
         res.op_at.push_back(res.out.size());
@@ -245,6 +245,36 @@ static bool run(int n, unsigned long long seed, int ops, bool jitter, Result &re
                 res.out.insert(res.out.end(), sig.begin(), sig.begin() + 3 * (ns + 1));
             }
             CK(wv_set_trajectory_stride(ctx, 1));
+        } else if (kind == 28 || kind == 29) {  // a SECOND context on the device for a while (this one then leaves the resident kernel
+                                                // to nobody: single-step kernels on both), stepped in turn with this one, then destroyed
+            wv_ctx *other = nullptr;
+            const int n2 = 96 + 32 * (int)(urand32() % 3);
+            std::vector<float> x2(n2);
+            for (int i = 0; i < n2; ++i) x2[i] = (float)(-15.0 + 30.0 * i / (n2 - 1));
+            wv_config cfg2{n2, n2, 1531.0f, dt, 2.0f, 20000.0f, 0, WV_IMPL_AUTO};
+            if (wv_create(&cfg2, x2.data(), x2.data(), &other) != 0) {
+                fprintf(stderr, "second context: %s\n", wv_last_error(nullptr));
+                return false;
+            }
+            std::vector<float> ts2(21), sg2(63);
+            bool ok2 = wv_set_gaussian_source(other, 1, mu, sigma, amp, 1000.0f) == 0;
+            for (int a = 0; a < 3 && ok2; ++a) {
+                for (int q = 0; q <= 20; ++q) ts2[q] = (float)((double)(a * 20 + q) * (double)dt);
+                ok2 = wv_set_design(other, M, pos.data(), r0.data(), c.data(), pos.data(), r0.data(), c.data(), ts2[0], ts2[20]) == 0 &&
+                      wv_integrate_begin(other, ts2.data(), 20, 1, 1, 0) == 0;
+                if (!begin()) return false;     // (this context's action while the other's is in flight)
+                if (kind == 29 && !begin()) return false;
+                ok2 = ok2 && wv_integrate_end(other, sg2.data(), nullptr, nullptr) == 0;
+                res.out.insert(res.out.end(), sg2.begin(), sg2.end());
+                pause();
+                if (!end()) return false;
+                if (kind == 29 && !end()) return false;
+            }
+            if (!ok2) {
+                fprintf(stderr, "second context: %s\n", wv_last_error(other));
+                return false;
+            }
+            if (wv_destroy(other) != 0) return false;
         } else {                  // an action without a design (NoDesign: C(t) = c0), then the design again
             for (int s2 = 0; s2 <= steps; ++s2) tspan[s2] = (float)((double)(step0 + s2) * (double)dt);
             CK(wv_set_design(ctx, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tspan[0], tspan[steps]));
@@ -254,6 +284,9 @@ static bool run(int n, unsigned long long seed, int ops, bool jitter, Result &re
             step0 += steps;
         }
     }
+    steps = 30;   // one more plain action, alone on the device: the context must be (back) on the resident kernel
+    fields = 0;
+    if (!begin() || !end()) return false;
     CK(wv_get_state(ctx, state.data()));
     res.out.insert(res.out.end(), state.begin(), state.begin() + (size_t)n * n);
     CK(wv_destroy(ctx));
