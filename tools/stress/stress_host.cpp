@@ -3,18 +3,19 @@
 // three, state(env), synchronize, reset, the state leaving and coming back -- is run twice per seed on a fresh context: once with
 // random host pauses of 0-60 us and a short idle limit of the launch, once undisturbed.  Every trace, observation and the final
 // frames must be the same bytes; a context that loses the resident kernel (give-up) is a failure too.
-//   stress_host [grid 320] [first_seed 0] [n_seeds 10] [ops 200] [need_resident 1] [second run on the single-step kernels 0]
+//   stress_host [grid 320] [first_seed 0] [n_seeds 10] [ops 200] [need_resident 1] [second run on the single-step kernels 0] [two threads 0]
 // build: make -C waves.jl_amd/csrc stress
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/waves_amd.h"
 
-static unsigned long long g_rng;
+static thread_local unsigned long long g_rng;
 static unsigned urand32()
 {
     g_rng = g_rng * 6364136223846793005ull + 1442695040888963407ull;
@@ -299,6 +300,29 @@ int main(int argc, char **argv)
     const int first = argc > 2 ? atoi(argv[2]) : 0, nseeds = argc > 3 ? atoi(argv[3]) : 10, ops = argc > 4 ? atoi(argv[4]) : 200;
     const bool need_resident = !(argc > 5 && atoi(argv[5]) == 0);  // 0: grids beyond the resident kernel (single-step kernels)
     const bool cross = argc > 6 && atoi(argv[6]) != 0;             // 1: the undisturbed run on the single-step kernels (resident vs single-step)
+    const bool threads = argc > 7 && atoi(argv[7]) != 0;           // 1: seeds s and s + 100000 at once, a context each on a thread of
+                                                                   //    its own (contexts are per thread: include/waves_amd.h), against
+                                                                   //    the same two run one after the other
+    if (threads) {
+        int badt = 0;
+        for (int s = first; s < first + nseeds; ++s) {
+            Result a0, a1, b0, b1;
+            bool ok0 = false, ok1 = false;
+            std::thread t0([&] { ok0 = run(n, (unsigned long long)s, ops, true, a0); });
+            std::thread t1([&] { ok1 = run(n, (unsigned long long)s + 100000ull, ops, true, a1); });
+            t0.join();
+            t1.join();
+            const bool okb = run(n, (unsigned long long)s, ops, false, b0) && run(n, (unsigned long long)s + 100000ull, ops, false, b1);
+            const bool same = ok0 && ok1 && okb && a0.out.size() == b0.out.size() && a1.out.size() == b1.out.size() &&
+                              memcmp(a0.out.data(), b0.out.data(), a0.out.size() * sizeof(float)) == 0 &&
+                              memcmp(a1.out.data(), b1.out.data(), a1.out.size() * sizeof(float)) == 0;
+            printf("seeds %d and %d on two threads: %zu + %zu values: %s\n", s, s + 100000, a0.out.size(), a1.out.size(), same ? "same bytes" : "FAILED");
+            fflush(stdout);
+            badt += same ? 0 : 1;
+        }
+        printf(badt ? "FAILED\n" : "PASS\n");
+        return badt ? 1 : 0;
+    }
     const int idles[6] = {10, 20, 35, 50, 80, 1000};
     int bad = 0;
     for (int s = first; s < first + nseeds; ++s) {
