@@ -341,6 +341,10 @@ def test_fast_host_stress_of_the_job_protocol():
     # right-hand side the same bytes whichever kernel integrated
     p = subprocess.run([exe, "320", "60", "6", "100", "1", "1"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and p.stdout.strip().endswith("PASS"), p.stdout[-1500:] + p.stderr[-500:]
+    # ... and two contexts driven from two threads at once (include/waves_amd.h: contexts may live on different threads)
+    # against the same two run one after the other
+    p = subprocess.run([exe, "256", "70", "3", "60", "0", "0", "1"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.strip().endswith("PASS"), p.stdout[-1500:] + p.stderr[-500:]
 
 
 def test_idle_limit_adapts_to_the_caller():
