@@ -131,7 +131,10 @@ int wv_get_source_shape(wv_ctx *ctx, float *shape /* nx*ny */);
  * out is (rx, ry, 4) column-major: U_tot of the three frames of env.wave, then the source shape (zeros for NoSource),
  * each resized on the device from (nx, ny) to (rx, ry); 1 <= rx <= nx, 1 <= ry <= ny (the reference asserts
  * size(dim) .> resolution, src/env.jl:52).  imresize belongs to Images.jl (third-party, unpinned): the rule implemented
- * is stated in kernels_aux.hip (k_observation); the test-suite's CPU restatement of it is imresize_linear. */
+ * is stated in kernels_aux.hip (k_observation); the test-suite's CPU restatement of it is imresize_linear.
+ * Needs no pending integrate call.  A waiting resident launch is not disturbed: after the first call at a resolution the
+ * following wv_integrate calls produce the observation of the frames they leave themselves (same arithmetic, into pinned
+ * memory; this call then is a copy), and one they have not produced is computed beside the launch on another stream. */
 int wv_observation(wv_ctx *ctx, int rx, int ry, float *out /* rx*ry*4 */);
 
 /* C = t -> speed(DesignInterpolator(initial, final, ti, tf)(t), grid, c0).  src/env.jl:95-99, src/designs.jl:274-292.
