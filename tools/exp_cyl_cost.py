@@ -10,8 +10,11 @@ import bench  # noqa: E402
 import waves_jl_amd as w  # noqa: E402
 
 
+GRID = int(os.environ.get("EXP_GRID", "700"))
+
+
 def run(name, ds, n=20):
-    dim = w.TwoDim(15.0, 700)
+    dim = w.TwoDim(15.0, GRID)
     src = w.RandomPosGaussianSource(w.build_grid(dim), [[-10.0, -10.0]], [[-10.0, 10.0]], [0.3], [1.0], 1000.0,
                                     rng=np.random.default_rng(2))
     env = w.WaveEnv(dim, design_space=ds, source=src, integration_steps=100, actions=n + 10, device=0, impl="fused",
