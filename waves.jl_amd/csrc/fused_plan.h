@@ -296,7 +296,11 @@ inline void plan_pair_order(HostPlan &pl, int pair_cus)
         const double fill = (double)(t.oy + 2 * FT_H) / RY;
         const double set = t.aux == AUX_NONE ? 1.0 : (t.aux == AUX_ALL ? W[2] : (t.aux == AUX_PX ? W[0] : W[1]));
         const int nc = t.cyl_count < 0 ? 8 : t.cyl_count;
-        return fill * set * (nc > 0 ? W[3] + W[4] * (nc - 1) : 1.0) * (t.edge ? W[5] : 1.0);
+        const double wt = fill * set * (nc > 0 ? W[3] + W[4] * (nc - 1) : 1.0) * (t.edge ? W[5] : 1.0);
+        // A strip or corner of the PML never counts lighter than a plain interior tile, however few rows it owns: the lightest
+        // tiles become the partners of the heaviest, and two PML strips on one CU are the worst pair there is (700^2: with
+        // the PY strips weighed 3 % lighter, i.e. below 1, an action takes 980 us instead of 890 -- measured, round 3).
+        return (t.aux != AUX_NONE && wt < 1.02) ? 1.02 : wt;
     };
     std::vector<std::pair<double, int>> key(n);  // (−weight, position): ascending sort = heaviest first, ties in order
     for (int i = 0; i < n; ++i) key[i] = {-weight(pl.tiles[i]), i};
