@@ -281,7 +281,7 @@ inline void plan_pair_order(HostPlan &pl, int pair_cus)
     if (!(pair_cus > 0 && pl.band_begin.size() == 2 && n > pair_cus && n <= 2 * pair_cus)) return;
     // relative cost of a tile: field set x rows in use x cylinders evaluated x boundary code.  WAVES_AMD_PAIR_W
     // ("px,py,all,cyl1,cylk,edge") overrides the factors (tuning runs).
-    static double W[6] = {1.22, 1.22, 1.75, 1.6, 0.2, 1.0};
+    static double W[6] = {1.22, 1.4, 2.0, 1.6, 0.2, 1.0};  // (end of round 3: py 1.22 -> 1.4 and all 1.75 -> 2.0 -- every corner tile a CU of its own --: -2.6 % at 700^2)
     static bool parsed = false;
     if (!parsed) {
         parsed = true;
