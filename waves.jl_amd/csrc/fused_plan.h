@@ -310,10 +310,63 @@ inline void plan_pair_order(HostPlan &pl, int pair_cus)
     // which of the two tiles of a CU is launched first (the older block wins the issue arbitration): the heavy one by
     // default; WAVES_AMD_PAIR_FLIP=1 (tuning runs) the light one
     static const bool flip = getenv("WAVES_AMD_PAIR_FLIP") && atoi(getenv("WAVES_AMD_PAIR_FLIP")) != 0;
+    // WHICH light tile joins which heavy one, and at which launch positions the pairs sit.  WAVES_AMD_PAIR_SHUFFLE=seed,what
+    // (experiments): what = 0 partners in weight order (ties in plan order: rounds 2 and 3 until the last day), 1 random partners,
+    // 2 random positions, 3 both, 4 ... 10 structured assignments (below)
+    std::vector<int> hpos(pairs), lsel(pairs);
+    for (int i = 0; i < pairs; ++i) hpos[i] = lsel[i] = i;
+    {
+        // Default (what = 5): the heavy tiles in ascending y take the light tiles in DESCENDING y -- found at the end of round 3:
+        // which light tile joins which heavy one decides 5 % of an action (random partners 880-893 us, partners in weight
+        // order with ties in plan order 864-872, this 840-847; a point reflection does as well, a half-domain shift does not).
+        unsigned long long seed = 0;
+        int what = 5;
+        if (const char *e = getenv("WAVES_AMD_PAIR_SHUFFLE")) (void)sscanf(e, "%llu,%d", &seed, &what);
+        auto rnd = [&]() { seed = seed * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)(seed >> 33); };
+        if (what == 4 || what == 5 || what == 6 || what == 7) {
+            // structured alternatives: heavy tiles in ascending y (4, 5) or x (6, 7) order take the light tiles in the same (4, 6)
+            // or the opposite (5, 7) order
+            std::vector<int> hi(pairs), li(pairs);
+            for (int i = 0; i < pairs; ++i) hi[i] = li[i] = i;
+            auto ky = [&](int idx) { const TileDesc &t = src[key[idx].second]; return what < 6 ? t.y0 * 4096 + t.x0 : t.x0 * 4096 + t.y0; };
+            std::sort(hi.begin(), hi.end(), [&](int a, int b) { return ky(alone + a) < ky(alone + b); });
+            std::sort(li.begin(), li.end(), [&](int a, int b) { return ky(n - 1 - a) < ky(n - 1 - b); });
+            for (int r = 0; r < pairs; ++r) lsel[hi[r]] = li[(what & 1) ? pairs - 1 - r : r];
+            what = 0;
+        }
+        if (what == 8 || what == 9 || what == 10) {
+            // the light partner nearest to the heavy tile's image under a half-domain shift (8), a point reflection (9), or a
+            // half-domain shift in y only (10): greedy, heavy tiles in weight order
+            std::vector<char> used(pairs, 0);
+            for (int i = 0; i < pairs; ++i) {
+                const TileDesc &h = src[key[alone + i].second];
+                const double hx = h.x0 + 0.5 * h.ox, hy = h.y0 + 0.5 * h.oy;
+                double tx = hx, ty = hy;
+                if (what == 8) tx = fmod(hx + 0.5 * pl.nx, (double)pl.nx), ty = fmod(hy + 0.5 * pl.ny, (double)pl.ny);
+                if (what == 9) tx = pl.nx - hx, ty = pl.ny - hy;
+                if (what == 10) ty = fmod(hy + 0.5 * pl.ny, (double)pl.ny);
+                int best = -1;
+                double bd = 1e300;
+                for (int j = 0; j < pairs; ++j) {
+                    if (used[j]) continue;
+                    const TileDesc &l = src[key[n - 1 - j].second];
+                    const double dx = l.x0 + 0.5 * l.ox - tx, dy = l.y0 + 0.5 * l.oy - ty, d = dx * dx + dy * dy;
+                    if (d < bd) bd = d, best = j;
+                }
+                used[best] = 1;
+                lsel[i] = best;
+            }
+            what = 0;
+        }
+        if (what & 1)
+            for (int i = pairs - 1; i > 0; --i) std::swap(lsel[i], lsel[rnd() % (unsigned)(i + 1)]);
+        if (what & 2)
+            for (int i = pairs - 1; i > 0; --i) std::swap(hpos[i], hpos[rnd() % (unsigned)(i + 1)]);
+    }
     for (int i = 0; i < alone; ++i) pl.tiles[pairs + i] = src[key[i].second];
     for (int i = 0; i < pairs; ++i) {
-        pl.tiles[flip ? C + i : i] = src[key[alone + i].second];
-        pl.tiles[flip ? i : C + i] = src[key[n - 1 - i].second];
+        pl.tiles[flip ? C + hpos[i] : hpos[i]] = src[key[alone + i].second];
+        pl.tiles[flip ? hpos[i] : C + hpos[i]] = src[key[n - 1 - lsel[i]].second];
     }
 }
 
