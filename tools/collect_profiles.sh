@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/${PROF_DIR:-prof}
 STEPS=${PROF_STEPS:-20}
 rm -rf "$OUT" && mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --cpu-steps 0 --batch-envs 0 --side-configs 0 --steps $STEPS --warmup 3 $*"
+BENCH="python3 $R/bench.py --cpu-steps 0 --batch-envs 0 --side-configs 0 --steps $STEPS --warmup 5 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- $BENCH > "$OUT/kt.log" 2>&1
 echo "kernel-trace rc=$?"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc1" -o p -- $BENCH > "$OUT/pmc1.log" 2>&1
