@@ -334,7 +334,7 @@ inline void plan_pair_order(HostPlan &pl, int pair_cus)
             for (int r = 0; r < pairs; ++r) lsel[hi[r]] = li[(what & 1) ? pairs - 1 - r : r];
             what = 0;
         }
-        if (what == 8 || what == 9 || what == 10) {
+        if (what == 8 || what == 9 || what == 10 || what == 11 || what == 12) {
             // the light partner nearest to the heavy tile's image under a half-domain shift (8), a point reflection (9), or a
             // half-domain shift in y only (10): greedy, heavy tiles in weight order
             std::vector<char> used(pairs, 0);
@@ -345,6 +345,8 @@ inline void plan_pair_order(HostPlan &pl, int pair_cus)
                 if (what == 8) tx = fmod(hx + 0.5 * pl.nx, (double)pl.nx), ty = fmod(hy + 0.5 * pl.ny, (double)pl.ny);
                 if (what == 9) tx = pl.nx - hx, ty = pl.ny - hy;
                 if (what == 10) ty = fmod(hy + 0.5 * pl.ny, (double)pl.ny);
+                if (what == 11) ty = pl.ny - hy;  // the mirror image about the horizontal axis
+                if (what == 12) tx = pl.nx - hx;  // ... about the vertical axis
                 int best = -1;
                 double bd = 1e300;
                 for (int j = 0; j < pairs; ++j) {
