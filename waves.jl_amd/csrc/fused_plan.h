@@ -323,6 +323,8 @@ inline void plan_pair_order(HostPlan &pl, int pair_cus)
         int what = 5;
         if (const char *e = getenv("WAVES_AMD_PAIR_SHUFFLE")) (void)sscanf(e, "%llu,%d", &seed, &what);
         auto rnd = [&]() { seed = seed * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)(seed >> 33); };
+        const int pos_rule = what >= 100 ? what / 100 : 0;  // (experiments: what = 100 * position rule + partner rule)
+        what %= 100;
         if (what == 4 || what == 5 || what == 6 || what == 7) {
             // structured alternatives: heavy tiles in ascending y (4, 5) or x (6, 7) order take the light tiles in the same (4, 6)
             // or the opposite (5, 7) order
@@ -359,6 +361,25 @@ inline void plan_pair_order(HostPlan &pl, int pair_cus)
                 lsel[i] = best;
             }
             what = 0;
+        }
+        if (pos_rule) {
+            // launch positions of the pairs: by the heavy tile's y (1), x (2), y interleaved from both ends (3), slot (4)
+            std::vector<int> ord(pairs);
+            for (int i = 0; i < pairs; ++i) ord[i] = i;
+            auto kk = [&](int i) {
+                const TileDesc &t = src[key[alone + i].second];
+                return pos_rule == 2 ? t.x0 * 4096 + t.y0 : (pos_rule == 4 ? t.slot : t.y0 * 4096 + t.x0);
+            };
+            std::sort(ord.begin(), ord.end(), [&](int a, int b) { return kk(a) < kk(b); });
+            if (pos_rule == 3) {
+                std::vector<int> o2;
+                for (int a = 0, b = pairs - 1; a <= b; ++a, --b) {
+                    o2.push_back(ord[a]);
+                    if (a != b) o2.push_back(ord[b]);
+                }
+                ord = o2;
+            }
+            for (int r = 0; r < pairs; ++r) hpos[ord[r]] = r;
         }
         if (what & 1)
             for (int i = pairs - 1; i > 0; --i) std::swap(lsel[i], lsel[rnd() % (unsigned)(i + 1)]);
