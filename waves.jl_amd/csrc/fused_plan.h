@@ -386,6 +386,25 @@ inline void plan_pair_order(HostPlan &pl, int pair_cus)
         if (what & 2)
             for (int i = pairs - 1; i > 0; --i) std::swap(hpos[i], hpos[rnd() % (unsigned)(i + 1)]);
     }
+    if (const char *pf = getenv("WAVES_AMD_PAIR_KEYS")) {
+        // (experiment, tools/exp_pair_search.py) one key per tile slot from a file: the heavy tiles in ascending key take the
+        // light tiles in descending key -- the default rule is this with key = y * 4096 + x
+        if (FILE *f = fopen(pf, "r")) {
+            std::vector<double> kv(n, 0.0);
+            bool ok = true;
+            for (int i = 0; i < n && ok; ++i) ok = fscanf(f, "%lf", &kv[i]) == 1;
+            fclose(f);
+            if (ok) {
+                std::vector<int> hi(pairs), li(pairs);
+                for (int i = 0; i < pairs; ++i) hi[i] = li[i] = i;
+                auto kh = [&](int i) { return kv[src[key[alone + i].second].slot]; };
+                auto kl = [&](int i) { return kv[src[key[n - 1 - i].second].slot]; };
+                std::stable_sort(hi.begin(), hi.end(), [&](int x, int y) { return kh(x) < kh(y); });
+                std::stable_sort(li.begin(), li.end(), [&](int x, int y) { return kl(x) < kl(y); });
+                for (int r = 0; r < pairs; ++r) lsel[hi[r]] = li[pairs - 1 - r];
+            }
+        }
+    }
     for (int i = 0; i < alone; ++i) pl.tiles[pairs + i] = src[key[i].second];
     for (int i = 0; i < pairs; ++i) {
         pl.tiles[flip ? C + hpos[i] : hpos[i]] = src[key[alone + i].second];
