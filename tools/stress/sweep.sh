@@ -5,7 +5,7 @@ set -u -o pipefail
 first=${1:-7000}
 per=${2:-12}
 bad=0
-for n in 96 128 200 256 320 450 500 550 600 660 700 720 800; do
+for n in 128 200 256 320 450 500 550 600 660 700 720 800; do
     for cross in 0 1; do
         out=$(timeout -k 10 240 tools/stress/stress_host $n $((first + n)) $per 160 0 $cross 0 2>&1 | tail -1)
         rc=$?
