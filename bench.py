@@ -320,7 +320,8 @@ def timed_rollout(env, policy, n_actions, in_flight=2):
         dev_ms += t["total_ms"]
         job_us.append(t["step_kernel_ms"] * 1e3 / max(t["step_kernel_launches"], 1))
 
-    with_state = getattr(timed_rollout, "with_state", False)   # --with-state: state(env) in front of every action (src/data.jl:23)
+    # --with-state: state(env) in front of every action (src/data.jl:23) -- of the loops that run one action at a time
+    with_state = getattr(timed_rollout, "with_state", False) and in_flight < 2
     prof = os.environ.get("WAVES_AMD_PYPROF")   # diagnostic: where the host's time per action goes (policy / begin / end)
     tp = [0.0, 0.0, 0.0]
     for k in range(n_actions):

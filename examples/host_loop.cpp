@@ -3,9 +3,10 @@
 // the Python mirror's interpreter time.  A TIMING example, not a parity test: coordinates, the triple-ring design and the
 // random actions are built here in plain C++ (the parity tests live in tests/ and go through the same entry points).
 //
-//   host_loop [grid 700] [actions 40] [in_flight 1|2] [state 0|1]
+//   host_loop [grid 700] [actions 40] [in_flight 1|2] [state 0|1] [pause_us 0]
 //     in_flight 1: every action is ended before the next one is begun (a policy that looks at the wave state);
-//     state 1:     wv_observation (state(env), 128x128x4) in front of every action.
+//     state 1:     wv_observation (state(env), 128x128x4) in front of every action;
+//     pause_us:    the host spins this long in front of every action (a policy that thinks).
 //   prints one JSON line: ms per action, Mcell-updates/s, the launch-level figures of wv_get_timing.
 //
 // build:  make -C waves.jl_amd/csrc example      (g++, links libwaves_amd.so; no HIP headers needed on this side)
@@ -39,6 +40,7 @@ int main(int argc, char **argv)
     const int actions = argc > 2 ? atoi(argv[2]) : 40;
     const int in_flight = argc > 3 ? atoi(argv[3]) : 1;
     const int with_state = argc > 4 ? atoi(argv[4]) : 0;
+    const double pause_us = argc > 5 ? atof(argv[5]) : 0.0;
     const int steps = 100, warm = 5;
     const float dt = 1e-5f;
     wv_ctx *ctx = nullptr;
@@ -71,6 +73,10 @@ int main(int argc, char **argv)
     double checksum = 0.0;
     int step0 = 0, begun = 0, ended = 0;
     auto begin = [&]() -> int {
+        if (pause_us > 0.0) {
+            const auto p0 = std::chrono::steady_clock::now();
+            while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - p0).count() < pause_us) {}
+        }
         if (with_state) CK(wv_observation(ctx, 128, 128, obs.data()));                 // s = state(env)
         for (int j = 0; j < 18; ++j) {                                                 // a = policy(s); design_space(design, a)
             const float a = scale * (2.0f * urand() - 1.0f);

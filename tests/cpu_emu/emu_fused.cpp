@@ -794,6 +794,41 @@ static int run_jobs(const char *name, int scenario)
     return fails;
 }
 
+// plan_pair_order's per-call code (only the tiles with cylinders are sorted) against its generic code: the same launch order,
+// tile for tile, over grids whose tiles pair up on `cus` compute units and random designs
+static int check_pair_order(int n, int cus, int M, int rounds)
+{
+    std::vector<float> x(n), sx(n, 0.0f);
+    for (int i = 0; i < n; ++i) x[i] = (float)(-15.0 + 30.0 * i / (n - 1));
+    for (int i = 0; i < n; ++i) {
+        const double d = std::min(x[i] + 15.0, 15.0 - (double)x[i]);
+        sx[i] = d < 2.0 ? (float)(20000.0 * (2.0 - d) / 2.0) : 0.0f;
+    }
+    HostPlan pa, pb;
+    if (!plan_build_tiles(pa, n, n, 32, 24, 16, x.data(), x.data(), sx.data(), sx.data(), true, true)) return 1;
+    pb = pa;
+    const int nt = (int)pa.tiles.size();
+    int bad = 0;
+    std::vector<Cyl> ends((size_t)2 * M);
+    std::vector<int> ia, ib;
+    for (int r = 0; r < rounds; ++r) {
+        const int m_now = r % 5 == 4 ? 0 : M;  // (also: no design at all)
+        for (int e = 0; e < 2; ++e)
+            for (int m = 0; m < M; ++m) {
+                const double rad = 0.2 + 1.8 * urand();
+                ends[(size_t)e * M + m] = Cyl{(float)(-12.0 + 24.0 * urand()), (float)(-12.0 + 24.0 * urand()), (float)(rad * rad), 1000.0f};
+            }
+        g_plan_pair_generic = 0;
+        plan_build_cyl(pa, x.data(), x.data(), ends.data(), m_now, 2, ia, true, cus, 0, 1);
+        g_plan_pair_generic = 1;
+        plan_build_cyl(pb, x.data(), x.data(), ends.data(), m_now, 2, ib, true, cus, 0, 1);
+        g_plan_pair_generic = 0;
+        if (pa.tiles.size() != pb.tiles.size() || memcmp(pa.tiles.data(), pb.tiles.data(), pa.tiles.size() * sizeof(TileDesc)) != 0 || ia != ib) ++bad;
+    }
+    printf("%-36s %s (%d tiles on %d CUs, %d designs)\n", "pair order: per-call code = generic", bad ? "MISMATCH" : "ok", nt, cus, rounds);
+    return bad ? 1 : 0;
+}
+
 int main(int argc, char **argv)
 {
     const bool quick = argc > 1 && !strcmp(argv[1], "quick");
@@ -833,6 +868,9 @@ int main(int argc, char **argv)
     }
     int fails = 0;
     for (const Case &c : cases) fails += run_case(c);
+    fails += check_pair_order(700, 256, 19, quick ? 20 : 200);
+    fails += check_pair_order(700, 240, 5, quick ? 10 : 60);    // (another split into tiles alone / pairs)
+    fails += check_pair_order(420, 100, 30, quick ? 10 : 60);
     fails += run_jobs("jobs: plain sequence", 0);
     fails += run_jobs("jobs: a launch that ends with a job", 1);
     fails += run_jobs("jobs: idle limit, new launch", 2);

@@ -22,6 +22,13 @@ struct HostPlan {
                                     // x-strips, so a band's tiles only read halo cells of the two adjacent bands
     int count[4] = {0, 0, 0, 0};    // tiles per field set
     bool monotonic = true;          // x[] and y[] strictly increasing (needed for bounding-box culling)
+    // plan_pair_order's per-tiling tables (built on first use, dropped by plan_build_tiles): the weight order of the tiles when
+    // none evaluates a cylinder, and their geometric order -- a call then only sorts the tiles that DO evaluate cylinders
+    int pair_static_for = 0;        // the pair_cus the tables were made for (0: none)
+    std::vector<double> pair_w0;    // [base position] weight without cylinders
+    std::vector<int> pair_ord0;     // base positions by (descending weight, position)
+    std::vector<int> pair_geo;      // base positions by (y0, x0)
+    std::vector<TileDesc> pair_out; // scratch
 };
 
 // n cells starting at `first` in pieces of at most omax, sizes differing by at most one (never a sliver: a run of
@@ -168,6 +175,7 @@ inline bool plan_build_tiles(HostPlan &pl, int nx, int ny, int RYF, int RYB, int
     pl.RYB = RYB;
     pl.RYP = RYP;
     pl.tiles.clear();
+    pl.pair_static_for = 0;
     for (int &c : pl.count) c = 0;
     pl.monotonic = true;
     for (int i = 1; i < nx; ++i)
@@ -275,6 +283,7 @@ inline bool plan_build_tiles(HostPlan &pl, int nx, int ny, int RYF, int RYB, int
 // time of a plain interior tile; two tiles sharing a CU take ~1.3x the time of the slower one alone.  Pairing the two
 // kinds of PML strip with each other instead of with light interior tiles costs 9 %.)  L2 locality is irrelevant here:
 // resident tiles exchange halos through memory.  Placement only affects speed, never results.
+inline int g_plan_pair_generic = 0;  // tests: != 0 makes plan_pair_order take its generic code
 inline void plan_pair_order(HostPlan &pl, int pair_cus)
 {
     const int n = (int)pl.tiles.size();
@@ -302,11 +311,73 @@ inline void plan_pair_order(HostPlan &pl, int pair_cus)
         // the PY strips weighed 3 % lighter, i.e. below 1, an action takes 980 us instead of 890 -- measured, round 3).
         return (t.aux != AUX_NONE && wt < 1.02) ? 1.02 : wt;
     };
+    const int C = pair_cus, alone = 2 * C - n, pairs = n - C;
+    static const bool plain = !getenv("WAVES_AMD_PAIR_SHUFFLE") && !getenv("WAVES_AMD_PAIR_KEYS") && !getenv("WAVES_AMD_PAIR_GENERIC") &&
+                              !(getenv("WAVES_AMD_PAIR_FLIP") && atoi(getenv("WAVES_AMD_PAIR_FLIP")) != 0);
+    if (plain && !g_plan_pair_generic && pl.tiles.size() == pl.base.size()) {
+        // The product's rule (below: weight order, partner rule 5) without sorting all tiles per call -- this runs on the host in
+        // front of every call, also of those whose tiles cull their cylinders themselves.  pl.tiles is in base order here (the
+        // caller's culling starts from pl.base); only tiles that evaluate cylinders weigh differently from call to call.
+        // Same result as the generic code (tests/test_plan_cpu.py compares the two; WAVES_AMD_PAIR_GENERIC=1 forces that code).
+        if (pl.pair_static_for != C || (int)pl.pair_w0.size() != n) {
+            pl.pair_w0.resize(n);
+            pl.pair_ord0.resize(n);
+            pl.pair_geo.resize(n);
+            for (int i = 0; i < n; ++i) {
+                TileDesc t = pl.base[i];
+                t.cyl_begin = t.cyl_count = 0;
+                pl.pair_w0[i] = weight(t);
+                pl.pair_ord0[i] = pl.pair_geo[i] = i;
+            }
+            std::sort(pl.pair_ord0.begin(), pl.pair_ord0.end(), [&](int a, int b) {
+                return pl.pair_w0[a] != pl.pair_w0[b] ? pl.pair_w0[a] > pl.pair_w0[b] : a < b;
+            });
+            std::sort(pl.pair_geo.begin(), pl.pair_geo.end(), [&](int a, int b) {
+                const TileDesc &ta = pl.base[a], &tb = pl.base[b];
+                return ta.y0 * 4096 + ta.x0 < tb.y0 * 4096 + tb.x0;
+            });
+            pl.pair_static_for = C;
+        }
+        // the tiles with cylinders, heaviest first
+        std::pair<double, int> cyl[JOB_MAX_TILES];
+        int nc = 0;
+        for (int i = 0; i < n && nc < JOB_MAX_TILES; ++i)
+            if (pl.tiles[i].cyl_count != 0) cyl[nc++] = {-weight(pl.tiles[i]), i};
+        std::sort(cyl, cyl + nc);
+        // merged with the rest: rank[position] in the order (descending weight, position)
+        int rank[JOB_MAX_TILES];
+        if (n <= JOB_MAX_TILES) {
+            int a = 0, b = 0, r = 0;
+            while (r < n) {
+                while (a < n && pl.tiles[pl.pair_ord0[a]].cyl_count != 0) ++a;
+                const bool take_cyl = b < nc && (a >= n || std::make_pair(cyl[b].first, cyl[b].second) <
+                                                               std::make_pair(-pl.pair_w0[pl.pair_ord0[a]], pl.pair_ord0[a]));
+                if (take_cyl) rank[cyl[b++].second] = r++;
+                else rank[pl.pair_ord0[a++]] = r++;
+            }
+            std::vector<TileDesc> &out = pl.pair_out;
+            out.resize(n);
+            // heavy tiles in ascending (y, x) take the light tiles in descending (y, x)
+            int hl[JOB_MAX_TILES], ll[JOB_MAX_TILES], nh = 0, nl = 0;
+            for (int g = 0; g < n; ++g) {
+                const int i = pl.pair_geo[g], r2 = rank[i];
+                if (r2 < alone) out[pairs + r2] = pl.tiles[i];
+                else if (r2 < alone + pairs) hl[nh++] = i;
+                else ll[nl++] = i;
+            }
+            for (int r2 = 0; r2 < pairs; ++r2) {
+                const int h = hl[r2], l = ll[pairs - 1 - r2], i = rank[h] - alone;
+                out[i] = pl.tiles[h];
+                out[C + i] = pl.tiles[l];
+            }
+            pl.tiles.swap(out);
+            return;
+        }
+    }
     std::vector<std::pair<double, int>> key(n);  // (−weight, position): ascending sort = heaviest first, ties in order
     for (int i = 0; i < n; ++i) key[i] = {-weight(pl.tiles[i]), i};
     std::sort(key.begin(), key.end());
     const std::vector<TileDesc> src = pl.tiles;
-    const int C = pair_cus, alone = 2 * C - n, pairs = n - C;
     // which of the two tiles of a CU is launched first (the older block wins the issue arbitration): the heavy one by
     // default; WAVES_AMD_PAIR_FLIP=1 (tuning runs) the light one
     static const bool flip = getenv("WAVES_AMD_PAIR_FLIP") && atoi(getenv("WAVES_AMD_PAIR_FLIP")) != 0;
@@ -450,6 +521,14 @@ inline void plan_build_cyl(HostPlan &pl, const float *x, const float *y, const C
         const double rr = rad + std::max(mx, my);  // inflated radius; box = swept centres grown by rr
         box[m] = Box{pxmin - rr, pxmax + rr, pymin - rr, pymax + rr, rr, ok};
     }
+    // (the box around ALL the cylinders' boxes: a tile outside it is missed by each of them -- four compares instead of M tests
+    // for most tiles of a grid whose design sits in one part of it; this loop is host time in front of every call)
+    double ux0 = INFINITY, ux1 = -INFINITY, uy0 = INFINITY, uy1 = -INFINITY;
+    bool all_ok = true;
+    for (const Box &b : box) {
+        all_ok = all_ok && b.ok;
+        ux0 = std::min(ux0, b.x0), ux1 = std::max(ux1, b.x1), uy0 = std::min(uy0, b.y0), uy1 = std::max(uy1, b.y1);
+    }
     for (TileDesc &t : pl.tiles) {
         if (!pl.monotonic) {
             t.cyl_begin = 0;
@@ -461,6 +540,7 @@ inline void plan_build_cyl(HostPlan &pl, const float *x, const float *y, const C
         const double xa = x[rx0], xb = x[rx1], ya = y[ry0], yb = y[ry1];
         t.cyl_begin = (int)idx.size();
         t.cyl_count = 0;
+        if (all_ok && (ux1 < xa || ux0 > xb || uy1 < ya || uy0 > yb)) continue;
         for (int m = 0; m < M; ++m) {
             const Box &b = box[m];
             bool miss = b.ok && (b.x1 < xa || b.x0 > xb || b.y1 < ya || b.y0 > yb);

@@ -713,6 +713,11 @@ struct FusedPlan {
     int cur = 0;                  // slot of the call being prepared / launched
     TileDesc *d_tiles[2] = {nullptr, nullptr};
     TileDesc *h_tiles[2] = {nullptr, nullptr};
+    // the launch order of a job WITHOUT host-built tables (fused_try_resident, dev): pinned host memory the blocks read their
+    // tile from directly, one buffer per job parity
+    TileDesc *h_order[2] = {nullptr, nullptr};
+    size_t order_cap[2] = {0, 0};
+    std::vector<Cyl> order_ends;             // the call's design at its earliest and latest stage time, [2][M]
     size_t tiles_cap[2] = {0, 0};
     int *d_idx[2] = {nullptr, nullptr};
     int *h_idx[2] = {nullptr, nullptr};
@@ -866,6 +871,7 @@ void fused_destroy(FusedPlan *p)
     for (int k = 0; k < 2; ++k) {
         if (p->d_tiles[k]) (void)hipFree(p->d_tiles[k]);
         if (p->d_snap[k]) (void)hipFree(p->d_snap[k]);
+        if (p->h_order[k]) (void)hipHostFree(p->h_order[k]);
         if (p->h_tiles[k]) (void)hipHostFree(p->h_tiles[k]);
         if (p->d_idx[k]) (void)hipFree(p->d_idx[k]);
         if (p->h_idx[k]) (void)hipHostFree(p->h_idx[k]);
@@ -1579,6 +1585,31 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
         p.cull_t_lo = dev->t_lo;
         p.cull_t_hi = dev->t_hi;
         p.tiles = pl->launch_tiles;
+        // The launch ORDER is made for this call's design (which two tiles share a CU, fused_plan.h plan_pair_order): the order an
+        // earlier call left behind goes stale as the design walks away from that call's -- 700^2, random radii, one action at a
+        // time: jobs of 868 us right after a call with tables, 915-955 us five actions later, 840-850 with this.  The culling
+        // of the call's two end designs and the sorts are host work in front of the bell (WAVES_AMD_DEV_ORDER=0: the old table);
+        // the table travels in pinned memory that every block reads its own 40 bytes of.
+        static const bool dev_order = !(getenv("WAVES_AMD_DEV_ORDER") && atoi(getenv("WAVES_AMD_DEV_ORDER")) == 0);
+        static const bool pairing = !(getenv("WAVES_AMD_FUSED_PAIRING") && atoi(getenv("WAVES_AMD_FUSED_PAIRING")) == 0);
+        if (dev_order && pairing && pl->hp.monotonic && (int)nt > pl->cu_count && (int)nt <= 2 * pl->cu_count) {
+            const int k = (int)(p.seq & 1u);
+            if (nt > pl->order_cap[k]) {
+                if (pl->h_order[k]) (void)hipHostFree(pl->h_order[k]);
+                pl->h_order[k] = nullptr;
+                pl->order_cap[k] = 0;
+                if (hipHostMalloc((void **)&pl->h_order[k], nt * sizeof(TileDesc), hipHostMallocDefault) != hipSuccess) return 1;
+                pl->order_cap[k] = nt;
+            }
+            pl->order_ends.resize((size_t)2 * dev->M);
+            for (int m = 0; m < dev->M; ++m) {
+                pl->order_ends[m] = design_cyl(desc.dsg, m, dev->t_lo);
+                pl->order_ends[(size_t)dev->M + m] = design_cyl(desc.dsg, m, dev->t_hi);
+            }
+            plan_build_cyl(pl->hp, pl->x.data(), pl->y.data(), pl->order_ends.data(), dev->M, 2, pl->idx, true, pl->cu_count, 0, 1);
+            memcpy(pl->h_order[k], pl->hp.tiles.data(), nt * sizeof(TileDesc));
+            p.tiles = pl->h_order[k];
+        }
     } else if (pl->snap_w >= 0) {
         pl->launch_tiles = pl->d_snap[pl->snap_w];
         pl->snap_w = -1;
