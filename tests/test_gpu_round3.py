@@ -375,3 +375,37 @@ def test_idle_limit_adapts_to_the_caller():
     env.ctx.synchronize()
     assert env.ctx.timing()["launch_jobs"] == 2          # ... and a 0.3 ms pause is waited out again
     env.ctx.close()
+
+
+def test_jobs_without_host_tables_get_their_own_launch_order_and_the_same_bytes(monkeypatch):
+    """A call whose tiles evaluate and cull their cylinders themselves (one action at a time: no host tables) runs in a launch
+    order made for its own design (fused_try_resident: the culling of the call's end designs and plan_pair_order on the host,
+    the table in pinned memory) -- placement only: traces, observations and final frames are the bytes of the same loop in
+    the order an earlier call left on the device (WAVES_AMD_DEV_ORDER=0) and with host tables for every call
+    (WAVES_AMD_DEV_TABLES=0 is read once per process, so that leg is the pipelined loop, whose calls carry host tables).
+    700^2: the size whose 467 tiles pair up on the 256 CUs."""
+    def run(order, pipelined):
+        gc.collect()
+        monkeypatch.setenv("WAVES_AMD_DEV_ORDER", "1" if order else "0")
+        env, pol = _env(700, 24, 100, 11)
+        out = []
+        if pipelined:
+            out += [s.copy() for s in w.rollout_pipelined(env, pol, 6)]
+        else:
+            for k in range(6):
+                if k == 3:
+                    out.append(np.array(env.state().wave))
+                env(pol(env))
+                out.append(env.signal.copy())
+        out.append(np.array(env.ctx.get_frames()))
+        t = env.ctx.timing()
+        env.ctx.close()
+        return out, t
+    a, ta = run(True, False)
+    b, tb = run(False, False)
+    c, tc = run(True, True)
+    assert ta["resident"] == 1 and tb["resident"] == 1 and tc["resident"] == 1 and ta["gave_up"] == 0
+    assert len(a) == len(b) == 8 and all(np.array_equal(x, y) for x, y in zip(a, b))
+    traces_a = [x for x in a if x.shape == (25, 3)]
+    assert len(traces_a) == 6 and all(np.array_equal(x, y) for x, y in zip(traces_a, c[:6]))
+    assert np.array_equal(a[-1], c[-1])

@@ -1590,7 +1590,8 @@ int fused_try_resident(FusedPlan *pl, int slot, const FusedCall &call, const Fus
         // time: jobs of 868 us right after a call with tables, 915-955 us five actions later, 840-850 with this.  The culling
         // of the call's two end designs and the sorts are host work in front of the bell (WAVES_AMD_DEV_ORDER=0: the old table);
         // the table travels in pinned memory that every block reads its own 40 bytes of.
-        static const bool dev_order = !(getenv("WAVES_AMD_DEV_ORDER") && atoi(getenv("WAVES_AMD_DEV_ORDER")) == 0);
+        const char *dev_order_env = getenv("WAVES_AMD_DEV_ORDER");  // (read per call: the tests compare the two in one process)
+        const bool dev_order = !(dev_order_env && atoi(dev_order_env) == 0);
         static const bool pairing = !(getenv("WAVES_AMD_FUSED_PAIRING") && atoi(getenv("WAVES_AMD_FUSED_PAIRING")) == 0);
         if (dev_order && pairing && pl->hp.monotonic && (int)nt > pl->cu_count && (int)nt <= 2 * pl->cu_count) {
             const int k = (int)(p.seq & 1u);
