@@ -28,7 +28,9 @@ struct HostPlan {
     std::vector<double> pair_w0;    // [base position] weight without cylinders
     std::vector<int> pair_ord0;     // base positions by (descending weight, position)
     std::vector<int> pair_geo;      // base positions by (y0, x0)
-    std::vector<TileDesc> pair_out; // scratch
+    std::vector<TileDesc> pair_out; // scratch of a call ...
+    std::vector<std::pair<double, int>> pair_cyl;
+    std::vector<int> pair_rank, pair_hl, pair_ll;
 };
 
 // n cells starting at `first` in pieces of at most omax, sizes differing by at most one (never a sliver: a run of
@@ -339,14 +341,18 @@ inline void plan_pair_order(HostPlan &pl, int pair_cus)
             pl.pair_static_for = C;
         }
         // the tiles with cylinders, heaviest first
-        std::pair<double, int> cyl[JOB_MAX_TILES];
-        int nc = 0;
-        for (int i = 0; i < n && nc < JOB_MAX_TILES; ++i)
-            if (pl.tiles[i].cyl_count != 0) cyl[nc++] = {-weight(pl.tiles[i]), i};
-        std::sort(cyl, cyl + nc);
+        std::vector<std::pair<double, int>> &cyl = pl.pair_cyl;
+        cyl.clear();
+        for (int i = 0; i < n; ++i)
+            if (pl.tiles[i].cyl_count != 0) cyl.push_back({-weight(pl.tiles[i]), i});
+        std::sort(cyl.begin(), cyl.end());
+        const int nc = (int)cyl.size();
         // merged with the rest: rank[position] in the order (descending weight, position)
-        int rank[JOB_MAX_TILES];
-        if (n <= JOB_MAX_TILES) {
+        std::vector<int> &rank = pl.pair_rank, &hl = pl.pair_hl, &ll = pl.pair_ll;
+        rank.resize(n);
+        hl.resize(n);
+        ll.resize(n);
+        {
             int a = 0, b = 0, r = 0;
             while (r < n) {
                 while (a < n && pl.tiles[pl.pair_ord0[a]].cyl_count != 0) ++a;
@@ -358,7 +364,7 @@ inline void plan_pair_order(HostPlan &pl, int pair_cus)
             std::vector<TileDesc> &out = pl.pair_out;
             out.resize(n);
             // heavy tiles in ascending (y, x) take the light tiles in descending (y, x)
-            int hl[JOB_MAX_TILES], ll[JOB_MAX_TILES], nh = 0, nl = 0;
+            int nh = 0, nl = 0;
             for (int g = 0; g < n; ++g) {
                 const int i = pl.pair_geo[g], r2 = rank[i];
                 if (r2 < alone) out[pairs + r2] = pl.tiles[i];
