@@ -30,6 +30,9 @@ def main():
     src = w.RandomPosGaussianSource(w.build_grid(dim), [[-10.0, -10.0]], [[-10.0, 10.0]], [0.3], [1.0], 1000.0)
     env = w.WaveEnv(dim, design_space=ds, source=src, integration_steps=args.steps, actions=args.actions, device=dev,
                     return_fields=False)
+    import gc
+    gc.collect()
+    gc.freeze()   # (as bench.py does: a collection that walks torch's objects in mid-episode stalls the host past a job's length)
     wd.barrier()
     t0 = time.perf_counter()
     rows = []
